@@ -1,0 +1,162 @@
+"""Generate tests/golden/*.npz by running the REAL reference (backend="torch", fp32, CPU)
+from /root/reference on seeded synthetic inputs and weights.  Container-only; the
+outputs (data, not code) are committed and travel to the GPU box.
+
+    python -m oracle.gen_golden [plugs] [video] [tiny]
+
+Weights: sam2_opt_amd.weights.synthetic_state_dict(cfg, seed=0)   (regenerated anywhere)
+Inputs : sam2_opt_amd.synthetic.*  with the seeds named below.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle.golden_io import pack  # noqa: E402
+from oracle.ref_import import build_reference_model  # noqa: E402
+from sam2_opt_amd.config import get_config  # noqa: E402
+from sam2_opt_amd.synthetic import normalize_frames, randn, synthetic_frames_u8, synthetic_image_normed  # noqa: E402
+from sam2_opt_amd.weights import synthetic_state_dict  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+BLOCKS = (0, 1, 2, 3, 7, 8, 9, 23, 43, 44, 47)
+VIDEO_FRAMES = 24
+CLICK = (512.0, 512.0)
+
+
+def plug_inputs(cfg):
+    """Seeded plug-level inputs shared with the tests (tests/plug_inputs mirrors by import)."""
+    C, M = cfg["d_model"], cfg["mem_dim"]
+    d = {}
+    for tag, L, P, seed in (("memattn_L1P4", 1, 4, 11), ("memattn_L3P12", 3, 12, 12), ("memattn_L1P0", 1, 0, 13)):
+        d[tag] = (randn(seed, 4096, 1, C), randn(seed + 100, L, 4096, 1, M), randn(seed + 200, 4096, 1, C),
+                  randn(seed + 300, L, 4096, 1, M), randn(seed + 400, P, 1, M), randn(seed + 500, P, 1, M))
+    for tag, N, T, seed in (("maskdec_N1T8", 1, 8, 21), ("maskdec_N2T15", 2, 15, 22)):
+        d[tag] = (randn(seed, N, C, 64, 64), randn(seed + 100, N, T, C), randn(seed + 200, N, C, 64, 64),
+                  randn(seed + 300, N, C // 8, 256, 256), randn(seed + 400, N, C // 4, 128, 128))
+    d["memenc"] = (randn(31, 1, C, 64, 64), randn(131, 1, 1, 1024, 1024, scale=4.0))
+    d["prompt"] = (torch.tensor([[[100.0, 200.0], [512.0, 512.0], [1000.5, 3.25]]]), torch.tensor([[1, 0, 1]], dtype=torch.int32))
+    d["samheads"] = (randn(41, 1, C, 64, 64), randn(141, 1, C // 8, 256, 256), randn(241, 1, C // 4, 128, 128))
+    return d
+
+
+@torch.inference_mode()
+def gen_plugs():
+    cfg = get_config("large")
+    sd = synthetic_state_dict(cfg, seed=0)
+    model = build_reference_model(cfg, "video", sd)
+    store = {}
+    t0 = time.time()
+    # ---- image encoder (config 2) + selected block outputs
+    img = synthetic_image_normed(seed=1)
+    blk = {}
+    hooks = [model.image_encoder.trunk.blocks[i].register_forward_hook(
+        lambda m, a, o, i=i: blk.__setitem__(i, o.detach().clone())) for i in BLOCKS]
+    outs = model.inference_image_torch(img)
+    for h in hooks:
+        h.remove()
+    names = ["vision_features", "vision_pos_enc0", "vision_pos_enc1", "vision_pos_enc2",
+             "backbone_fpn0", "backbone_fpn1", "backbone_fpn2"]
+    for n, o in zip(names, outs):
+        pack(store, "enc/" + n, o, 65536)
+    for i, o in blk.items():
+        pack(store, f"enc/block{i}", o, 32768)
+    print("encoder", time.time() - t0)
+    pin = plug_inputs(cfg)
+    for tag in ("memattn_L1P4", "memattn_L3P12", "memattn_L1P0"):
+        o = model.memory_attention.inference_memory_attention_torch(*pin[tag])
+        pack(store, tag, o, 65536)
+    for tag in ("maskdec_N1T8", "maskdec_N2T15"):
+        o = model.sam_mask_decoder.inference_predict_masks_torch(*pin[tag])
+        for n, t in zip(("masks", "iou", "tokens", "obj"), o):
+            pack(store, f"{tag}/{n}", t, 32768)
+    x, pos = model.memory_encoder.inference_memory_torch(*pin["memenc"])
+    pack(store, "memenc/x", x, 65536)
+    pack(store, "memenc/pos", pos, 16384)
+    sp, de = model.sam_prompt_encoder.inference_prompt_torch(pin["prompt"], None, None)
+    pack(store, "prompt/sparse", sp)
+    pack(store, "prompt/dense", de, 4096)
+    pack(store, "prompt/dense_pe", model.sam_prompt_encoder.get_dense_pe(), 65536)
+    for mm in (True, False):
+        o = model._forward_sam_heads(pin["samheads"][0], None, None, [pin["samheads"][1], pin["samheads"][2]], mm)
+        for n, t in zip(("low_multi", "high_multi", "ious", "low", "high", "obj_ptr", "obj_score"), o):
+            pack(store, f"samheads_mm{int(mm)}/{n}", t, 16384)
+    np.savez_compressed(os.path.join(GOLD, "large_plugs.npz"), **store)
+    print("plugs done", time.time() - t0)
+
+
+@torch.inference_mode()
+def gen_video():
+    cfg = get_config("large")
+    sd = synthetic_state_dict(cfg, seed=0)
+    model = build_reference_model(cfg, "video", sd, fill_hole_area=0)
+    frames = normalize_frames(synthetic_frames_u8(seed=2, num_frames=VIDEO_FRAMES), cfg)
+    import sam2.sam2_video_predictor_official as vp
+    vp.load_video_frames = lambda **kw: (frames, 1024, 1024)
+    store = {}
+    rec = {"t": None}
+    ma = model.memory_attention
+    orig_ex = ma.inference_memory_attention_exclude
+
+    def rec_memattn(*inputs):
+        out = orig_ex(*inputs)
+        t = rec["t"]
+        store[f"f{t}/LP"] = np.array([inputs[1].shape[0], inputs[4].shape[0]], dtype=np.int64)
+        for n, x in zip(("curr", "memory", "curr_pos", "memory_pos", "mem_ex", "mem_pos_ex"), inputs):
+            pack(store, f"f{t}/memattn_in/{n}", x, 2048)
+        pack(store, f"f{t}/memattn_out", out, 8192)
+        return out
+
+    ma.inference_memory_attention_exclude = rec_memattn
+    orig_heads = model._forward_sam_heads
+
+    def rec_heads(*a, **k):
+        o = orig_heads(*a, **k)
+        t = rec["t"]
+        for n, x in zip(("low_multi", "high_multi", "ious", "low", "high", "obj_ptr", "obj_score"), o):
+            if n != "high_multi":
+                pack(store, f"f{t}/heads/{n}", x, 4096)
+        return o
+
+    model._forward_sam_heads = rec_heads
+    t0 = time.time()
+    state = model.init_state(video_path="synthetic")
+    rec["t"] = "click"
+    _, _, vm = model.add_new_points_or_box(state, frame_idx=0, obj_id=1, points=np.array([CLICK], np.float32),
+                                           labels=np.array([1], np.int32))
+    pack(store, "click/video_res_mask", vm, 16384)
+    rec["t"] = "pre"
+    gen = model.propagate_in_video(state)
+    n = 0
+    while True:
+        rec["t"] = n          # frames are yielded in order 0..T-1
+        try:
+            fi, ids, vm = next(gen)
+        except StopIteration:
+            break
+        assert fi == n
+        pack(store, f"f{fi}/video_res_mask", vm, 8192)
+        out = state["output_dict_per_obj"][0]
+        cur = out["cond_frame_outputs"].get(fi) or out["non_cond_frame_outputs"][fi]
+        pack(store, f"f{fi}/maskmem_features", cur["maskmem_features"].float(), 8192)
+        print("frame", fi, time.time() - t0, flush=True)
+        n += 1
+    store["num_frames"] = np.array([n], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "large_video24.npz"), **store)
+    print("video done", time.time() - t0)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["plugs", "video"]
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    if "plugs" in which:
+        gen_plugs()
+    if "video" in which:
+        gen_video()

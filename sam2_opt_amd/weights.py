@@ -1,0 +1,231 @@
+"""state_dict contract + portable synthetic weights.
+
+`state_dict_spec(cfg)` enumerates every tensor name/shape that a SAM 2.1 video
+predictor checkpoint holds (903 tensors for hiera-large), i.e. what
+`build_sam._load_checkpoint` (/root/reference/sam2/sam2/build_sam.py:164-174)
+loads strictly.  The HIP backend packs its device weights from such a dict, so
+a real `sam2.1_hiera_large.pt["model"]` and the synthetic dict below are
+interchangeable.
+
+`synthetic_state_dict(cfg, seed)` regenerates identical weights on any box from
+`numpy.random.RandomState(crc32(key) ^ seed)` - no checkpoint has to travel.
+The distribution is chosen so that activations stay O(1) through the 48 Hiera
+blocks, softmax rows are clearly non-uniform (logit std ~2.5) and the discrete
+decisions of the SAM heads (object-score sign, IoU argmax) are not on a knife
+edge (SURVEY.md 8d "Discrete-decision hazard").
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+from .config import hiera_block_specs
+
+
+def state_dict_spec(cfg: dict) -> "OrderedDict[str, tuple]":
+    C = cfg["d_model"]
+    M = cfg["mem_dim"]
+    E = cfg["embed_dim"]
+    sd: "OrderedDict[str, tuple]" = OrderedDict()
+
+    def lin(prefix, out_f, in_f):
+        sd[prefix + ".weight"] = (out_f, in_f)
+        sd[prefix + ".bias"] = (out_f,)
+
+    def norm(prefix, n):
+        sd[prefix + ".weight"] = (n,)
+        sd[prefix + ".bias"] = (n,)
+
+    def conv(prefix, out_c, in_c, k):
+        sd[prefix + ".weight"] = (out_c, in_c, k, k)
+        sd[prefix + ".bias"] = (out_c,)
+
+    sd["maskmem_tpos_enc"] = (cfg["num_maskmem"], 1, 1, M)
+    sd["no_mem_embed"] = (1, 1, C)
+    sd["no_mem_pos_enc"] = (1, 1, C)
+    sd["no_obj_ptr"] = (1, C)
+    sd["no_obj_embed_spatial"] = (1, M)
+
+    # ---- image encoder (hieradet.py:169-271, image_encoder.py:45-100)
+    t = "image_encoder.trunk."
+    sd[t + "pos_embed"] = (1, E) + tuple(cfg["window_pos_embed_bkg_spatial_size"])
+    sd[t + "pos_embed_window"] = (1, E, cfg["window_spec"][0], cfg["window_spec"][0])
+    conv(t + "patch_embed.proj", E, 3, 7)
+    specs = hiera_block_specs(cfg)
+    for s in specs:
+        b = f"{t}blocks.{s['idx']}."
+        norm(b + "norm1", s["dim"])
+        lin(b + "attn.qkv", 3 * s["dim_out"], s["dim"])
+        lin(b + "attn.proj", s["dim_out"], s["dim_out"])
+        norm(b + "norm2", s["dim_out"])
+        lin(b + "mlp.layers.0", 4 * s["dim_out"], s["dim_out"])
+        lin(b + "mlp.layers.1", s["dim_out"], 4 * s["dim_out"])
+        if s["dim"] != s["dim_out"]:
+            lin(b + "proj", s["dim_out"], s["dim"])
+    chans = [s["dim_out"] for s in specs if s["stage_end"]][::-1]
+    for i, ch in enumerate(chans):
+        conv(f"image_encoder.neck.convs.{i}.conv", C, ch, 1)
+
+    conv("mask_downsample", 1, 1, 4)
+
+    # ---- memory attention (memory_attention.py:18-60, transformer.py:222-260)
+    for l in range(cfg["memattn_layers"]):
+        p = f"memory_attention.layers.{l}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            lin(p + "self_attn." + nm, C, C)
+        lin(p + "cross_attn_image.q_proj", C, C)
+        lin(p + "cross_attn_image.k_proj", C, M)
+        lin(p + "cross_attn_image.v_proj", C, M)
+        lin(p + "cross_attn_image.out_proj", C, C)
+        lin(p + "linear1", cfg["memattn_ffn"], C)
+        lin(p + "linear2", C, cfg["memattn_ffn"])
+        for n in ("norm1", "norm2", "norm3"):
+            norm(p + n, C)
+    norm("memory_attention.norm", C)
+
+    # ---- memory encoder (memory_encoder.py:19-60, :64-119, :140-168)
+    ch_in = 1
+    for i in range(4):
+        ch_out = ch_in * 4
+        conv(f"memory_encoder.mask_downsampler.encoder.{3 * i}", ch_out, ch_in, 3)
+        norm(f"memory_encoder.mask_downsampler.encoder.{3 * i + 1}", ch_out)
+        ch_in = ch_out
+    conv("memory_encoder.mask_downsampler.encoder.12", C, ch_in, 1)
+    conv("memory_encoder.pix_feat_proj", C, C, 1)
+    for l in range(2):
+        p = f"memory_encoder.fuser.layers.{l}."
+        sd[p + "gamma"] = (C,)
+        sd[p + "dwconv.weight"] = (C, 1, 7, 7)
+        sd[p + "dwconv.bias"] = (C,)
+        norm(p + "norm", C)
+        lin(p + "pwconv1", 4 * C, C)
+        lin(p + "pwconv2", C, 4 * C)
+    conv("memory_encoder.out_proj", M, C, 1)
+
+    # ---- prompt encoder (prompt_encoder.py:41-72)
+    pe = "sam_prompt_encoder."
+    sd[pe + "pe_layer.positional_encoding_gaussian_matrix"] = (2, C // 2)
+    for i in range(4):
+        sd[pe + f"point_embeddings.{i}.weight"] = (1, C)
+    sd[pe + "not_a_point_embed.weight"] = (1, C)
+    sd[pe + "mask_downscaling.0.weight"] = (4, 1, 2, 2)
+    sd[pe + "mask_downscaling.0.bias"] = (4,)
+    norm(pe + "mask_downscaling.1", 4)
+    sd[pe + "mask_downscaling.3.weight"] = (16, 4, 2, 2)
+    sd[pe + "mask_downscaling.3.bias"] = (16,)
+    norm(pe + "mask_downscaling.4", 16)
+    conv(pe + "mask_downscaling.6", C, 16, 1)
+    sd[pe + "no_mask_embed.weight"] = (1, C)
+
+    # ---- mask decoder (mask_decoder.py:53-112, transformer.py:51-180)
+    d = "sam_mask_decoder."
+    I = C // 2  # cross-attention internal dim (downsample_rate 2)
+    for l in range(cfg["dec_depth"]):
+        p = f"{d}transformer.layers.{l}."
+        for nm in ("q_proj", "k_proj", "v_proj"):
+            lin(p + "self_attn." + nm, C, C)
+        lin(p + "self_attn.out_proj", C, C)
+        norm(p + "norm1", C)
+        for nm in ("q_proj", "k_proj", "v_proj"):
+            lin(p + "cross_attn_token_to_image." + nm, I, C)
+        lin(p + "cross_attn_token_to_image.out_proj", C, I)
+        norm(p + "norm2", C)
+        lin(p + "mlp.layers.0", cfg["dec_mlp"], C)
+        lin(p + "mlp.layers.1", C, cfg["dec_mlp"])
+        norm(p + "norm3", C)
+        norm(p + "norm4", C)
+        for nm in ("q_proj", "k_proj", "v_proj"):
+            lin(p + "cross_attn_image_to_token." + nm, I, C)
+        lin(p + "cross_attn_image_to_token.out_proj", C, I)
+    p = d + "transformer.final_attn_token_to_image."
+    for nm in ("q_proj", "k_proj", "v_proj"):
+        lin(p + nm, I, C)
+    lin(p + "out_proj", C, I)
+    norm(d + "transformer.norm_final_attn", C)
+    sd[d + "iou_token.weight"] = (1, C)
+    sd[d + "mask_tokens.weight"] = (4, C)
+    sd[d + "obj_score_token.weight"] = (1, C)
+    sd[d + "output_upscaling.0.weight"] = (C, C // 4, 2, 2)
+    sd[d + "output_upscaling.0.bias"] = (C // 4,)
+    norm(d + "output_upscaling.1", C // 4)
+    sd[d + "output_upscaling.3.weight"] = (C // 4, C // 8, 2, 2)
+    sd[d + "output_upscaling.3.bias"] = (C // 8,)
+    conv(d + "conv_s0", C // 8, C, 1)
+    conv(d + "conv_s1", C // 4, C, 1)
+    for i in range(4):
+        p = f"{d}output_hypernetworks_mlps.{i}.layers."
+        lin(p + "0", C, C)
+        lin(p + "1", C, C)
+        lin(p + "2", C // 8, C)
+    p = d + "iou_prediction_head.layers."
+    lin(p + "0", C, C)
+    lin(p + "1", C, C)
+    lin(p + "2", 4, C)
+    p = d + "pred_obj_score_head.layers."
+    lin(p + "0", C, C)
+    lin(p + "1", C, C)
+    lin(p + "2", 1, C)
+
+    for i in range(3):
+        lin(f"obj_ptr_proj.layers.{i}", C, C)
+    lin("obj_ptr_tpos_proj", M, C)
+    return sd
+
+
+def _kind(key: str, shape: tuple) -> str:
+    last = key.rsplit(".", 1)[-1]
+    if key.endswith("gamma"):
+        return "gamma"
+    if "positional_encoding_gaussian_matrix" in key:
+        return "gauss"
+    if last == "bias":
+        return "bias"
+    if len(shape) == 1:
+        return "norm_w"
+    if last == "weight" and len(shape) >= 2:
+        if "_embed" in key and "patch_embed" not in key or "_token" in key or "point_embeddings" in key:
+            return "embed"
+        return "matrix"
+    return "embed"  # bare nn.Parameters: pos_embed, no_mem_embed, maskmem_tpos_enc, ...
+
+
+def synthetic_tensor(key: str, shape: tuple, seed: int = 0) -> np.ndarray:
+    rs = np.random.RandomState((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF)
+    z = rs.standard_normal(shape).astype(np.float32)
+    kind = _kind(key, shape)
+    if kind == "matrix":
+        if "output_upscaling" in key and len(shape) == 4:   # ConvTranspose2d: (in, out, k, k)
+            fan_in = shape[0]
+        else:
+            fan_in = int(np.prod(shape[1:]))
+        gain = 1.0
+        if any(s in key for s in ("attn.qkv", "q_proj", "k_proj")):
+            gain = 1.6          # logit std ~2.5: softmax rows far from uniform
+        w = z * np.float32(gain / np.sqrt(fan_in))
+    elif kind == "bias":
+        w = z * np.float32(0.05)
+        if key.endswith("pred_obj_score_head.layers.2.bias"):
+            w = w + np.float32(3.0)           # object present unless a test flips it
+    elif kind == "norm_w":
+        w = np.float32(1.0) + np.float32(0.1) * z
+    elif kind == "gamma":
+        w = np.float32(0.5) + np.float32(0.1) * z
+    elif kind == "gauss":
+        w = z
+    else:  # embeddings / positional tables
+        w = z * np.float32(0.3)
+    return np.ascontiguousarray(w, dtype=np.float32)
+
+
+def synthetic_state_dict(cfg: dict, seed: int = 0, as_torch: bool = True):
+    spec = state_dict_spec(cfg)
+    out = OrderedDict()
+    for k, shp in spec.items():
+        a = synthetic_tensor(k, shp, seed)
+        if as_torch:
+            import torch
+            a = torch.from_numpy(a)
+        out[k] = a
+    return out

@@ -1,0 +1,81 @@
+"""Pin the CPU oracle (oracle/sam2_ref.py) to golden vectors produced by the REAL reference
+(oracle/gen_golden.py, run in the build container against /root/reference).  CPU only."""
+import pytest
+import torch
+
+from oracle import sam2_ref as R
+from oracle.gen_golden import BLOCKS, plug_inputs
+from oracle.golden_io import compare
+from sam2_opt_amd.synthetic import synthetic_image_normed
+
+ATOL = 2e-4   # fp32 CPU, different op order than the reference in a few places
+
+
+def _check(store, name, t, atol=ATOL):
+    ok, msg = compare(store, name, t, atol=atol, rtol=1e-4)
+    assert ok, msg
+
+
+@pytest.fixture(scope="module")
+def enc_out(sd_large, cfg_large):
+    torch.manual_seed(0)
+    blocks = {i: None for i in BLOCKS}
+    with torch.inference_mode():
+        outs = R.image_encoder(synthetic_image_normed(seed=1), sd_large, cfg_large, blocks)
+    return outs, blocks
+
+
+def test_encoder_outputs(enc_out, golden_plugs):
+    outs, _ = enc_out
+    names = ["vision_features", "vision_pos_enc0", "vision_pos_enc1", "vision_pos_enc2",
+             "backbone_fpn0", "backbone_fpn1", "backbone_fpn2"]
+    for n, o in zip(names, outs):
+        _check(golden_plugs, "enc/" + n, o, atol=5e-4)
+
+
+def test_encoder_blocks(enc_out, golden_plugs):
+    _, blocks = enc_out
+    for i, o in blocks.items():
+        _check(golden_plugs, f"enc/block{i}", o, atol=5e-4)
+
+
+@pytest.mark.parametrize("tag", ["memattn_L1P4", "memattn_L3P12", "memattn_L1P0"])
+def test_memory_attention(tag, sd_large, cfg_large, golden_plugs):
+    with torch.inference_mode():
+        o = R.memory_attention(*plug_inputs(cfg_large)[tag], sd_large, cfg_large)
+    _check(golden_plugs, tag, o)
+
+
+@pytest.mark.parametrize("tag", ["maskdec_N1T8", "maskdec_N2T15"])
+def test_mask_decoder(tag, sd_large, cfg_large, golden_plugs):
+    with torch.inference_mode():
+        o = R.predict_masks(*plug_inputs(cfg_large)[tag], sd_large, cfg_large)
+    for n, t in zip(("masks", "iou", "tokens", "obj"), o):
+        _check(golden_plugs, f"{tag}/{n}", t, atol=1e-3 if n == "masks" else ATOL)
+
+
+def test_memory_encoder(sd_large, cfg_large, golden_plugs):
+    with torch.inference_mode():
+        x, pos = R.memory_encoder(*plug_inputs(cfg_large)["memenc"], sd_large, cfg_large)
+    _check(golden_plugs, "memenc/x", x)
+    _check(golden_plugs, "memenc/pos", pos)
+
+
+def test_prompt_encoder(sd_large, cfg_large, golden_plugs):
+    pts, lab = plug_inputs(cfg_large)["prompt"]
+    with torch.inference_mode():
+        sp, de = R.prompt_encoder(pts, lab, sd_large, cfg_large)
+        _check(golden_plugs, "prompt/sparse", sp)
+        _check(golden_plugs, "prompt/dense", de)
+        _check(golden_plugs, "prompt/dense_pe", R.dense_pe(sd_large, cfg_large))
+
+
+@pytest.mark.parametrize("mm", [True, False])
+def test_sam_heads(mm, sd_large, cfg_large, golden_plugs):
+    pix, hr0, hr1 = plug_inputs(cfg_large)["samheads"]
+    with torch.inference_mode():
+        o = R.sam_heads(pix, hr0, hr1, sd_large, cfg_large, multimask_output=mm)
+    keys = dict(low_multi="low_res_multimasks", high_multi="high_res_multimasks", ious="ious", low="low_res_masks",
+                high="high_res_masks", obj_ptr="obj_ptr", obj_score="object_score_logits")
+    for g, k in keys.items():
+        _check(golden_plugs, f"samheads_mm{int(mm)}/{g}", o[k], atol=1e-3)
