@@ -1,0 +1,37 @@
+// Attention kernels (see the .hip files for the algorithms).
+#pragma once
+#include "common.h"
+
+// ---- Hiera head_dim-72 attention (attn_hiera.hip)
+struct HieraAttnParams {
+  const half_t* q; int ldq;     // [Mq, ldq] f16; head h at columns [h*72, h*72+72)
+  const half_t* k; int ldk;     // [Mk, ldk] f16; same head layout
+  const half_t* vT; int ldvT;   // V^T [heads*72, ldvT] f16: row h*72+d, column = key row index
+  half_t* o; int ldo;           // [Mq, ldo] f16 output, same head layout
+  int heads;
+  int GQ, GK;                   // queries / keys per group; group g owns q rows [g*GQ, (g+1)*GQ), keys [g*GK, ...)
+  int wq, wk;                   // query i sees key j (indices inside the group) iff i / wq == j / wk
+  int num_groups;
+  float scale_log2e;            // head_dim^-0.5 * log2(e)
+};
+hipError_t hiera_attn_launch(const HieraAttnParams& p, hipStream_t stream);
+
+// ---- single-head d=256 flash attention with split-KV (attn_flash256.hip)
+struct Flash256Params {
+  const half_t* q; int ldq;     // [Nq, ldq] f16 (RoPE already applied), Nq % 128 == 0
+  const half_t* k; int ldk;     // [>= ceil32(Nk), ldk] f16
+  const half_t* vT; int ldvT;   // V^T [256, ldvT] f16, ldvT >= ceil32(Nk); pad columns must be finite
+  int Nq, Nk;
+  int splits;                   // KV splits (grid.y)
+  float* o_part;                // [splits, Nq, 256] f32 un-normalised partial outputs
+  float* ml_part;               // [splits, Nq, 2] f32 (running max in log2 domain, running sum)
+  half_t* out; int ldout;       // [Nq, ldout] f16 final (written by the combine pass)
+  float scale_log2e;
+};
+hipError_t flash256_launch(const Flash256Params& p, hipStream_t stream);
+
+// ---- tiny fp32 attentions of the two-way mask decoder (attn_small.hip)
+// q [Tq, ldq], k/v [Tk, ld], heads x hd, out [Tq, ldo]; all f32.  softmax(q k^T / sqrt(hd)) v
+hipError_t small_attn_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                             float* out, int ldo, int Tq, int Tk, int heads, int hd, int batch,
+                             size_t q_bstride, size_t kv_bstride, size_t o_bstride, hipStream_t stream);

@@ -1,0 +1,62 @@
+// Common types and helpers for the gfx950 (MI355X / CDNA4) SAM2 kernels.
+// Wavefront = 64 lanes; MFMA fragments follow the gfx950 32x32x16 f16 maps:
+//   A: lane l holds A[row l&31][k = 8*(l>>5) + j], j = 0..7
+//   B: lane l holds B[k = 8*(l>>5) + j][col l&31]
+//   C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5), reg in [0,16)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+static __device__ __forceinline__ f32x16 mfma32(half8 a, half8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// row of accumulator register `reg` for this lane inside a 32x32 tile
+static __device__ __forceinline__ int acc_row(int reg, int lane) {
+  return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+}
+
+static __device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+static __device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware block remap (8 XCDs, blocks dealt round-robin): give each XCD a contiguous
+// chunk of the logical grid so neighbouring tiles share an L2.  Bijective for any nwg.
+static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + loc;
+}
+
+// window-major token order helpers: a (H x W) grid cut into w x w windows, windows row-major,
+// tokens row-major inside a window.
+static __host__ __device__ __forceinline__ int tok_of_yx(int y, int x, int W, int w) {
+  return ((y / w) * (W / w) + (x / w)) * (w * w) + (y % w) * w + (x % w);
+}
+
+#define HIP_CHECK_RET(expr)                                                        \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) return sam2mi_set_error(ctx, #expr, hipGetErrorString(_e)); \
+  } while (0)

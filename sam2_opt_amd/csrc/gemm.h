@@ -1,0 +1,37 @@
+// MFMA GEMM with fused epilogues:  C[M,N] = epi( A[M,K] (f16) . W[N,K]^T (f16) ), f32 accumulate.
+// Both operands are K-contiguous (activations row-major, weights in nn.Linear layout), which is
+// exactly the gfx950 32x32x16 fragment layout (8 consecutive k per lane).
+#pragma once
+#include "common.h"
+
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
+
+struct GemmParams {
+  const half_t* A; int lda;      // [M, lda] f16, lda % 8 == 0
+  const half_t* W; int ldw;      // [N, ldw] f16, ldw % 8 == 0
+  int M, N, K;                   // K % 32 == 0 (or % 48)
+  const float* bias;             // [N] or null
+  int act;                       // ACT_*
+  const float* col_scale;        // [N] or null: v = v * col_scale[n] (after act; CXBlock gamma)
+  const float* res; int ldres;   // optional f32 residual added last; row index = res_mod ? m % res_mod : m
+  int res_mod;
+  float* out32; int ld32;        // optional f32 row-major output (columns < n_split)
+  half_t* out16; int ld16;       // optional f16 row-major output (columns < n_split)
+  int n_split;                   // columns >= n_split are stored transposed; multiple of 32; == N if unused
+  half_t* outT16; int ldT16;     // outT16[(n - n_split) * ldT16 + m]  (ldT16 % 4 == 0)
+  float* outT32; int ldT32;      // outT32[(n - n_split) * ldT32 + m]
+  // axial RoPE fused on columns n < rope_cols of rows m < rope_rows (rope_cols == 0: off):
+  //   the pair (2p, 2p+1), p = (n % rope_dim) / 2, is rotated by the angle in table row m % rope_len
+  const float* rope_cos; const float* rope_sin;  // [rope_len, rope_dim/2]
+  int rope_len, rope_rows, rope_cols, rope_dim;
+};
+
+static inline GemmParams gemm_params_zero() {
+  GemmParams p;
+  __builtin_memset(&p, 0, sizeof(p));
+  return p;
+}
+
+// returns hipSuccess or an error; `flops`/`launches` accumulate statistics when non-null
+hipError_t gemm_launch(const GemmParams& p, hipStream_t stream);
+hipError_t gemm_init();   // sets the dynamic-LDS attributes once

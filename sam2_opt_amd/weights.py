@@ -174,6 +174,10 @@ def state_dict_spec(cfg: dict) -> "OrderedDict[str, tuple]":
     return sd
 
 
+DAMP_CROSS = 0.3
+DAMP_MEMOUT = 0.3
+
+
 def _kind(key: str, shape: tuple) -> str:
     last = key.rsplit(".", 1)[-1]
     if key.endswith("gamma"):
@@ -203,6 +207,14 @@ def synthetic_tensor(key: str, shape: tuple, seed: int = 0) -> np.ndarray:
         gain = 1.0
         if any(s in key for s in ("attn.qkv", "q_proj", "k_proj")):
             gain = 1.6          # logit std ~2.5: softmax rows far from uniform
+        # Damp the recurrent loop mask -> memory -> cross-attention -> mask.  With O(1) gains a
+        # random-weight tracker is chaotic (a 1e-4 perturbation grows ~3x per frame, which also
+        # happens between the reference and itself under a different fp32 summation order), so
+        # end-to-end parity over 100 frames would measure chaos, not arithmetic.
+        if "cross_attn_image.out_proj" in key:
+            gain = DAMP_CROSS
+        if key.startswith("memory_encoder.out_proj"):
+            gain = DAMP_MEMOUT
         w = z * np.float32(gain / np.sqrt(fan_in))
     elif kind == "bias":
         w = z * np.float32(0.05)

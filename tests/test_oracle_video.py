@@ -1,0 +1,44 @@
+"""Oracle video loop (memory-bank assembly, SAM-head selection, memory encoder, bf16 bank
+rounding) vs golden vectors from the real reference's propagate_in_video on the first frames
+of the synthetic config-3 clip.  CPU only; frames beyond ORACLE_VIDEO_FRAMES (default 9: L grows
+1..7, P 4..32) are covered when the env var is raised to 24."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import sam2_ref as R
+from oracle.gen_golden import CLICK, VIDEO_FRAMES
+from oracle.golden_io import compare
+from sam2_opt_amd.synthetic import normalize_frames, synthetic_frames_u8
+
+NF = int(os.environ.get("ORACLE_VIDEO_FRAMES", "9"))
+
+
+def test_video_oracle_matches_reference(sd_large, cfg_large, golden_video):
+    g = golden_video
+    assert int(g["num_frames"][0]) == VIDEO_FRAMES
+    frames = normalize_frames(synthetic_frames_u8(seed=2, num_frames=VIDEO_FRAMES), cfg_large)
+    vo = R.VideoOracle(sd_large, cfg_large, frames)
+    with torch.inference_mode():
+        vm = vo.add_new_points(0, np.array([CLICK], np.float32), np.array([1], np.int32))
+        ok, msg = compare(g, "click/video_res_mask", vm, atol=2e-3, rtol=1e-3)
+        assert ok, msg
+        for t, vm in vo.propagate(max_frames=NF - 1):
+            ok, msg = compare(g, f"f{t}/video_res_mask", vm, atol=5e-3, rtol=1e-3)
+            assert ok, msg
+            if t == 0:
+                ok, msg = compare(g, "f0/maskmem_features", vo.cond[0]["maskmem_features"].float(), atol=2e-3, rtol=8e-3)  # 1 bf16 ulp
+                assert ok, msg
+                continue
+            tr = vo.trace[("track", t)]
+            L, P = (int(v) for v in g[f"f{t}/LP"])
+            assert tr["memattn_in"][1].shape[0] == L and tr["memattn_in"][4].shape[0] == P
+            for n, x in zip(("curr", "memory", "curr_pos", "memory_pos", "mem_ex", "mem_pos_ex"), tr["memattn_in"]):
+                ok, msg = compare(g, f"f{t}/memattn_in/{n}", x, atol=2e-3, rtol=8e-3 if n in ("memory", "mem_ex") else 1e-3)
+                assert ok, msg
+            ok, msg = compare(g, f"f{t}/memattn_out", tr["pix_feat"].flatten(2).permute(2, 0, 1), atol=5e-3, rtol=1e-3)
+            assert ok, msg
+            for gk, k in (("ious", "ious"), ("obj_ptr", "obj_ptr"), ("obj_score", "object_score_logits"), ("low", "low_res_masks")):
+                ok, msg = compare(g, f"f{t}/heads/{gk}", tr[k], atol=5e-3, rtol=1e-3)
+                assert ok, msg
