@@ -1,0 +1,158 @@
+/* sam2mi - C ABI of the MI355X-native SAM 2.1 backend (libsam2mi.so).
+ *
+ * This is the drop-in boundary for the reference's backend plug layer.  The reference swaps six
+ * function-pointer attributes with `predictor.speedup(backend)` / `module.set_runtime_backend()`
+ * and expects an executor object with `Inference(list[Tensor]) -> list[Tensor]`
+ * (`from ytools.executor import ModelExectuor`, un-vendored submodule).  Each entry point below
+ * replaces one of those plugs; the Python adapter in sam2_opt_amd/plugin.py binds them with ctypes
+ * and installs them on the reference's modules.
+ *
+ * Conventions: every pointer is a DEVICE pointer to contiguous fp32 data in the reference's own
+ * layout (NCHW / sequence-first) unless stated otherwise; `stream` is a hipStream_t (pass
+ * torch.cuda.current_stream().cuda_stream); inputs are borrowed for the call, outputs are caller
+ * allocated; nothing synchronises the host.  Returns 0 on success, non-zero on error
+ * (message: sam2mi_last_error).  No C++ exceptions cross this boundary.
+ * A context is not re-entrant: use one context per host thread/stream.
+ *
+ * Paths below are relative to /root/reference/sam2/sam2/.
+ */
+#ifndef SAM2MI_H
+#define SAM2MI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sam2mi_ctx sam2mi_ctx;
+
+/* Hiera / model hyper-parameters (configs/sam2.1/sam2.1_hiera_l.yaml:1-120). */
+typedef struct sam2mi_config {
+  int embed_dim;             /* 144 */
+  int num_heads;             /* 2 */
+  int stages[4];             /* 2, 6, 36, 4 */
+  int global_att_blocks[8];  /* 23, 33, 43, -1 ... */
+  int window_spec[4];        /* 8, 4, 16, 8 */
+  int image_size;            /* 1024 */
+  int max_batch;             /* largest B of sam2mi_image_encoder / sam2mi_video_encode (workspace size) */
+  int bank_slots;            /* capacity of the device-resident memory bank of the video path */
+  int feat_slots;            /* capacity of the device-resident frame-feature cache of the video path */
+} sam2mi_config;
+
+int sam2mi_abi_version(void);
+int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out);
+void sam2mi_destroy(sam2mi_ctx* ctx);
+const char* sam2mi_last_error(sam2mi_ctx* ctx);   /* ctx may be NULL: last creation error */
+
+/* Weight loading - replaces build_sam._load_checkpoint (build_sam.py:164-174): call once per
+ * state_dict entry with a HOST pointer to fp32 data, then sam2mi_finalize_weights (packs f16 MFMA
+ * operands, fused projection matrices and the input-independent tables). Unknown keys are an error,
+ * missing keys are reported by finalize (strict, like load_state_dict). */
+int sam2mi_load_weight(sam2mi_ctx* ctx, const char* key, const float* host_data, const int64_t* shape, int ndim);
+int sam2mi_finalize_weights(sam2mi_ctx* ctx);
+
+/* ---- plug: SAM2Base.inference_image (modeling/sam2_base_official.py:548-582)
+ * img [B,3,1024,1024] normalised -> out[0..6] = vision_features (B,256,64,64), vision_pos_enc0..2
+ * (B,256,{256,128,64}^2), backbone_fpn0 (B,32,256,256), backbone_fpn1 (B,64,128,128),
+ * backbone_fpn2 (B,256,64,64).  Any out[i] may be NULL (skipped). */
+int sam2mi_image_encoder(sam2mi_ctx* ctx, void* stream, const float* img, int B, float* const out[7]);
+
+/* ---- plug: SAM2ImagePredictor.set_image_e2e (sam2_image_predictor.py:252-266)
+ * img01 [B,3,1024,1024] in [0,1] -> feat0 (B,32,256,256), feat1 (B,64,128,128), feat2 (B,256,64,64)
+ * (Normalize and "+ no_mem_embed" included). */
+int sam2mi_set_image_e2e(sam2mi_ctx* ctx, void* stream, const float* img01, int B, float* feat0, float* feat1, float* feat2);
+
+/* ---- plug: MemoryAttention.inference_memory_attention_{none,exclude} (modeling/memory_attention.py:294-349)
+ * curr (4096,N,256), memory (L,4096,N,64), curr_pos (4096,N,256), memory_pos (L,4096,N,64),
+ * memory_exclude (P,N,64), memory_pos_exclude (P,N,64) -> out (4096,N,256).  N must be 1. */
+int sam2mi_memory_attention(sam2mi_ctx* ctx, void* stream, const float* curr, const float* memory, const float* curr_pos,
+                            const float* memory_pos, const float* memory_exclude, const float* memory_pos_exclude,
+                            int L, int P, int N, float* out);
+
+/* ---- plug: MaskDecoder.inference_predict_masks (modeling/sam/mask_decoder.py:222-316)
+ * src (N,256,64,64), tokens (N,T,256), pos_src (N,256,64,64), hr0 (N,32,256,256), hr1 (N,64,128,128)
+ * -> masks (N,4,256,256), iou_pred (N,4), mask_tokens_out (N,4,256), object_score_logits (N,1). */
+int sam2mi_mask_decoder(sam2mi_ctx* ctx, void* stream, const float* src, const float* tokens, const float* pos_src,
+                        const float* hr0, const float* hr1, int N, int T, float* masks, float* iou_pred,
+                        float* mask_tokens_out, float* object_score_logits);
+
+/* ---- plug: MemoryEncoder.inference_memory (modeling/memory_encoder.py:228-241)
+ * pix_feat (N,256,64,64), masks (N,1,1024,1024) already sigmoid-scaled -> x (N,64,64,64), pos (N,64,64,64). */
+int sam2mi_memory_encoder(sam2mi_ctx* ctx, void* stream, const float* pix_feat, const float* masks, int N, float* x, float* pos);
+
+/* ---- plug: PromptEncoder.inference_prompt (modeling/sam/prompt_encoder.py:215-231), points only
+ * coords (B,Np,2) px, labels (B,Np) int32 -> sparse (B,Np+1,256), dense (B,256,64,64) [no_mask_embed]. */
+int sam2mi_prompt_encoder(sam2mi_ctx* ctx, void* stream, const float* coords, const int32_t* labels, int B, int Np,
+                          float* sparse, float* dense);
+/* PromptEncoder.get_dense_pe (prompt_encoder.py:113-122) -> (1,256,64,64) */
+int sam2mi_dense_pe(sam2mi_ctx* ctx, void* stream, float* out);
+
+/* ============================================================================================
+ * Fused video path: device-resident frame features and memory bank, no host sync, no layout
+ * round-trips between the plugs.  Host code (sam2_opt_amd/video_predictor.py) keeps the
+ * reference's state machine (sam2_video_predictor_official.py:651-736, sam2_base_official.py:797-976)
+ * and passes slot indices.
+ * ============================================================================================ */
+
+/* Encode B frames (B <= max_batch) and keep their features in feature-cache slots feat_slot[i]. */
+int sam2mi_video_encode(sam2mi_ctx* ctx, void* stream, const float* frames, int B, const int32_t* feat_slots);
+
+/* Which memories / object pointers a tracked frame attends to (SAM2Base._prepare_memory_conditioned_features). */
+typedef struct sam2mi_mem_select {
+  int num_mem;               /* L: spatial memories, in concatenation order */
+  int mem_slot[16];          /* bank slot of each */
+  int mem_tpos[16];          /* index into maskmem_tpos_enc (= num_maskmem - t_pos - 1) */
+  int num_ptr;               /* object pointers, in concatenation order */
+  int ptr_slot[32];          /* bank slot of each */
+  float ptr_dt[32];          /* signed temporal distance (frame_idx - t) */
+  float ptr_tmax;            /* max_obj_ptrs_in_encoder - 1 */
+} sam2mi_mem_select;
+
+/* Outputs of one frame of the fused path (all device pointers, any may be NULL). */
+typedef struct sam2mi_frame_out {
+  float* low_res_masks;      /* (1,1,256,256) selected mask logits */
+  float* low_res_multimasks; /* (1,3,256,256) or (1,1,256,256) */
+  float* ious;               /* (1,3) or (1,1) */
+  float* obj_ptr;            /* (1,256) */
+  float* object_score_logits;/* (1,1) */
+  float* pix_feat;           /* (4096,1,256) memory-conditioned features (debug/parity) */
+  int32_t* best_idx;         /* (1) chosen multimask candidate */
+} sam2mi_frame_out;
+
+/* Conditioning frame with point prompts (add_new_points_or_box -> track_step, is_init_cond_frame):
+ * SAM heads on feat + no_mem_embed; stores obj_ptr / score / low-res mask in bank slot `bank_slot`. */
+int sam2mi_video_click(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int Np,
+                       int multimask, int bank_slot, const sam2mi_frame_out* out);
+
+/* Memory encoder for a bank slot (propagate_in_video_preflight / _encode_new_memory): uses the low-res
+ * mask and object score stored in the slot, writes the bf16-rounded memory features into the slot. */
+int sam2mi_video_encode_memory(sam2mi_ctx* ctx, void* stream, int feat_slot, int bank_slot, int is_mask_from_pts);
+
+/* Tracked frame: memory attention over `sel`, SAM heads (multimask), memory encoder; result in `bank_slot`. */
+int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, const sam2mi_mem_select* sel, int bank_slot,
+                       int run_mem_encoder, const sam2mi_frame_out* out);
+
+/* Bilinear resize (align_corners=False) of a (H_in,W_in) fp32 map, F.interpolate semantics
+ * (_get_orig_video_res_output, sam2_video_predictor_official.py:489-509). */
+int sam2mi_resize_bilinear(sam2mi_ctx* ctx, void* stream, const float* in, int C, int Hin, int Win, float* out, int Hout, int Wout);
+
+/* Profiling hook for bench.py: when enabled, every MFMA GEMM launch is bracketed by HIP events on its
+ * own stream; totals are read back with sam2mi_profile_read (synchronises). */
+int sam2mi_profile_enable(sam2mi_ctx* ctx, int on);
+int sam2mi_profile_read(sam2mi_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches,
+                        double* attn_ms, double* attn_flops, int64_t* attn_launches);
+
+/* Debug/test entry points: single kernels behind the C ABI (used by tests/test_kernels_gpu.py). */
+int sam2mi_debug_gemm(sam2mi_ctx* ctx, void* stream, const float* A, const float* W, const float* bias, int M, int N, int K,
+                      int act, const float* residual, float* out);
+int sam2mi_debug_hiera_attention(sam2mi_ctx* ctx, void* stream, const float* q, const float* k, const float* v, int groups,
+                                 int heads, int GQ, int GK, int wq, int wk, float* out);
+int sam2mi_debug_flash256(sam2mi_ctx* ctx, void* stream, const float* q, const float* k, const float* v, int Nq, int Nk, float* out);
+int sam2mi_debug_hiera_block(sam2mi_ctx* ctx, void* stream, int block_idx, const float* x_nhwc, int B, float* out_nhwc);
+int sam2mi_debug_read(sam2mi_ctx* ctx, void* stream, const char* name, float* out, int64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAM2MI_H */

@@ -29,7 +29,7 @@ def pack(store: dict, name: str, t, target: int = 16384):
     store[name + "/shape"] = np.array(a.shape, dtype=np.int64)
 
 
-def compare(store, name: str, t, atol: float, rtol: float = 0.0, stat_rtol: float = 1e-4):
+def compare(store, name: str, t, atol: float, rtol: float = 0.0, stat_rtol: float = 1e-4, outlier_frac: float = 0.0):
     """Returns (ok, message).  `t` is the oracle's full tensor."""
     a = t.detach().to(torch.float32).cpu().numpy().reshape(-1)
     stride, size = (int(v) for v in store[name + "/meta"])
@@ -39,9 +39,15 @@ def compare(store, name: str, t, atol: float, rtol: float = 0.0, stat_rtol: floa
     got = a[::stride]
     err = np.abs(got - ref)
     tol = atol + rtol * np.abs(ref)
-    if not np.all(err <= tol):
+    bad = int((err > tol).sum())
+    if bad > outlier_frac * err.size:
         i = int(np.argmax(err - tol))
-        return False, f"{name}: max abs err {err.max():.3e} at sample {i} (ref {ref[i]:.6f} got {got[i]:.6f}), atol {atol}"
+        return False, (f"{name}: {bad}/{err.size} samples beyond tolerance; max abs err {err.max():.3e} at sample {i} "
+                       f"(ref {ref[i]:.6f} got {got[i]:.6f}), atol {atol}")
+    if outlier_frac > 0:
+        # discontinuous quantities (binarised masks, bf16 rounding): only the bulk is comparable
+        l2 = float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-12))
+        return (l2 <= 50 * (rtol + atol)), f"{name}: ok with {bad} outliers (max err {err.max():.2e}, rel L2 {l2:.2e})"
     f64 = a.astype(np.float64)
     stats = np.array([f64.sum(), np.abs(f64).sum(), (f64 * f64).sum()])
     g = store[name + "/stats"]

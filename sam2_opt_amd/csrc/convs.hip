@@ -1,0 +1,141 @@
+// Memory-encoder convolution kernels (MaskDownSampler / CXBlock of
+// /root/reference/sam2/sam2/modeling/memory_encoder.py:19-119) on NHWC ("token-major") tensors.
+#include "kernels.h"
+
+namespace {
+
+// bilinear x4 (align_corners=False, F.interpolate semantics) + sigmoid/binarize + affine
+__global__ void mask_prep_kernel(const float* __restrict__ low, float* __restrict__ out, int binarize, float scale, float bias) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 1024 * 1024) return;
+  const int y = i >> 10, x = i & 1023;
+  float sy = (y + 0.5f) * 0.25f - 0.5f, sx = (x + 0.5f) * 0.25f - 0.5f;
+  sy = fmaxf(sy, 0.f);
+  sx = fmaxf(sx, 0.f);
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = min(y0 + 1, 255), x1 = min(x0 + 1, 255);
+  const float ly = sy - y0, lx = sx - x0;
+  const float v = (1.f - ly) * ((1.f - lx) * low[y0 * 256 + x0] + lx * low[y0 * 256 + x1]) +
+                  ly * ((1.f - lx) * low[y1 * 256 + x0] + lx * low[y1 * 256 + x1]);
+  const float m = binarize ? (v > 0.f ? 1.f : 0.f) : 1.f / (1.f + expf(-v));
+  out[i] = m * scale + bias;
+}
+
+// one thread = one output pixel, all COUT channels in registers; weights (COUT, CIN, 3, 3) staged in LDS
+template <int CIN, int COUT>
+__global__ __launch_bounds__(128) void conv3x3s2_ln_gelu_kernel(const float* __restrict__ in, int Hin, const float* __restrict__ w,
+                                                                 const float* __restrict__ b, const float* __restrict__ lnw,
+                                                                 const float* __restrict__ lnb, float* out32, half_t* out16) {
+  __shared__ float sw[COUT * CIN * 9];
+  for (int i = threadIdx.x; i < COUT * CIN * 9; i += blockDim.x) sw[i] = w[i];
+  __syncthreads();
+  const int Hout = Hin / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Hout * Hout) return;
+  const int oy = i / Hout, ox = i % Hout;
+  float acc[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) acc[o] = b[o];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy * 2 - 1 + ky;
+    if (iy < 0 || iy >= Hin) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox * 2 - 1 + kx;
+      if (ix < 0 || ix >= Hin) continue;
+      const float* ip = in + ((size_t)iy * Hin + ix) * CIN;
+#pragma unroll 4
+      for (int c = 0; c < CIN; ++c) {
+        const float v = ip[c];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[o] += v * sw[(o * CIN + c) * 9 + ky * 3 + kx];
+      }
+    }
+  }
+  float mean = 0.f;
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) mean += acc[o];
+  mean /= COUT;
+  float var = 0.f;
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) var += (acc[o] - mean) * (acc[o] - mean);
+  const float rstd = 1.f / sqrtf(var / COUT + 1e-6f);
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) {
+    const float y = gelu_erf((acc[o] - mean) * rstd * lnw[o] + lnb[o]);
+    if (out32) out32[(size_t)i * COUT + o] = y;
+    if (out16) out16[(size_t)i * COUT + o] = (half_t)y;
+  }
+}
+
+__global__ void im2col3x3s2_kernel(const half_t* __restrict__ in, int Hin, int CIN, half_t* __restrict__ A) {
+  const int Hout = Hin / 2;
+  const int cpr = 9 * CIN / 8;                       // 8-wide chunks per output row
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)Hout * Hout * cpr) return;
+  const int ch = (int)(i % cpr);
+  const int pix = (int)(i / cpr);
+  const int oy = pix / Hout, ox = pix % Hout;
+  const int k = ch * 8, tap = k / CIN, c = k % CIN;  // CIN % 8 == 0: a chunk never straddles taps
+  const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
+  half8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
+  if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin) v = *reinterpret_cast<const half8*>(in + ((size_t)iy * Hin + ix) * CIN + c);
+  *reinterpret_cast<half8*>(A + (size_t)pix * 9 * CIN + k) = v;
+}
+
+__global__ void dwconv7_kernel(const float* __restrict__ in, int H, int C, const float* __restrict__ w, const float* __restrict__ b,
+                               float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)H * H * C) return;
+  const int c = (int)(i % C);
+  const int pix = (int)(i / C);
+  const int y = pix / H, x = pix % H;
+  float acc = b[c];
+  for (int ky = 0; ky < 7; ++ky) {
+    const int iy = y - 3 + ky;
+    if (iy < 0 || iy >= H) continue;
+    for (int kx = 0; kx < 7; ++kx) {
+      const int ix = x - 3 + kx;
+      if (ix < 0 || ix >= H) continue;
+      acc += in[((size_t)iy * H + ix) * C + c] * w[c * 49 + ky * 7 + kx];
+    }
+  }
+  out[i] = acc;
+}
+}  // namespace
+
+hipError_t mask_prep_launch(const float* low, float* out, int binarize, float scale, float bias, hipStream_t s) {
+  mask_prep_kernel<<<dim3(4096), dim3(256), 0, s>>>(low, out, binarize, scale, bias);
+  return hipGetLastError();
+}
+
+hipError_t conv3x3s2_ln_gelu_launch(const float* in, int Hin, int CIN, int COUT, const float* w, const float* b,
+                                    const float* lnw, const float* lnb, float* out32, half_t* out16, hipStream_t s) {
+  const int n = (Hin / 2) * (Hin / 2);
+  const dim3 grid((n + 127) / 128), block(128);
+  if (CIN == 1 && COUT == 4)
+    conv3x3s2_ln_gelu_kernel<1, 4><<<grid, block, 0, s>>>(in, Hin, w, b, lnw, lnb, out32, out16);
+  else if (CIN == 4 && COUT == 16)
+    conv3x3s2_ln_gelu_kernel<4, 16><<<grid, block, 0, s>>>(in, Hin, w, b, lnw, lnb, out32, out16);
+  else if (CIN == 16 && COUT == 64)
+    conv3x3s2_ln_gelu_kernel<16, 64><<<grid, block, 0, s>>>(in, Hin, w, b, lnw, lnb, out32, out16);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t im2col3x3s2_launch(const half_t* in, int Hin, int CIN, half_t* A, hipStream_t s) {
+  if (CIN % 8) return hipErrorInvalidValue;
+  const size_t total = (size_t)(Hin / 2) * (Hin / 2) * (9 * CIN / 8);
+  im2col3x3s2_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(in, Hin, CIN, A);
+  return hipGetLastError();
+}
+
+hipError_t dwconv7_launch(const float* in, int H, int C, const float* w, const float* b, float* out, hipStream_t s) {
+  const size_t total = (size_t)H * H * C;
+  dwconv7_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(in, H, C, w, b, out);
+  return hipGetLastError();
+}

@@ -1,0 +1,201 @@
+// Memory-bound helper kernels of the image encoder and the glue around the GEMMs.
+#include "kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------ LayerNorm: one wave per row
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float eps, int M, int C,
+                                                        half_t* y16, int ldy16, float* y32, int ldy32, int act) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * ldx;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)C;
+  float v = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float d = xr[c] - mean;
+    v += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
+  for (int c = lane; c < C; c += 64) {
+    float y = (xr[c] - mean) * rstd * w[c] + b[c];
+    if (act == 1) y = gelu_erf(y);
+    if (y16) y16[(size_t)row * ldy16 + c] = (half_t)y;
+    if (y32) y32[(size_t)row * ldy32 + c] = y;
+  }
+}
+
+__global__ void cast_add_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int bmod,
+                                float sb, int M, int C, half_t* y16, int ldy16, float* y32, int ldy32) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * C) return;
+  const int m = (int)(i / C), c = (int)(i % C);
+  float v = a[(size_t)m * lda + c];
+  if (b) v += sb * b[(size_t)(bmod ? m % bmod : m) * ldb + c];
+  if (y16) y16[(size_t)m * ldy16 + c] = (half_t)v;
+  if (y32) y32[(size_t)m * ldy32 + c] = v;
+}
+
+// ------------------------------------------------------------------ patch-embed im2col
+// one thread = one (token, 8-wide k chunk); 20 chunks per token (K padded 147 -> 160)
+__global__ void im2col_patch_kernel(const float* __restrict__ img, int B, int S, half_t* __restrict__ A) {
+  const int G = S / 4;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * G * G * 20;
+  if (i >= total) return;
+  const int ch = (int)(i % 20);
+  const size_t tok = i / 20;
+  const int b = (int)(tok / ((size_t)G * G));
+  const int t = (int)(tok % ((size_t)G * G));
+  // window-major (w = 8) token -> (y, x)
+  const int win = t >> 6, in = t & 63;
+  const int wpr = G / 8;
+  const int y = (win / wpr) * 8 + (in >> 3), x = (win % wpr) * 8 + (in & 7);
+  half8 out;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = ch * 8 + j;
+    float v = 0.f;
+    if (k < 147) {
+      const int c = k / 49, r = k % 49, ky = r / 7, kx = r % 7;
+      const int iy = y * 4 - 3 + ky, ix = x * 4 - 3 + kx;
+      if (iy >= 0 && iy < S && ix >= 0 && ix < S) v = img[(((size_t)b * 3 + c) * S + iy) * S + ix];
+    }
+    out[j] = (half_t)v;
+  }
+  *reinterpret_cast<half8*>(A + tok * 160 + ch * 8) = out;
+}
+
+// ------------------------------------------------------------------ 2x2 max-pool inside windows
+template <typename T>
+__global__ void pool_tokens_kernel(const T* __restrict__ in, int ldin, T* __restrict__ out, int ldout, int nwin, int w, int C) {
+  const int hw = w / 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)nwin * hw * hw * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const size_t ot = i / C;
+  const int win = (int)(ot / (hw * hw)), p = (int)(ot % (hw * hw));
+  const int py = p / hw, px = p % hw;
+  const T* base = in + ((size_t)win * w * w) * ldin + c;
+  float m = -3.0e38f;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) m = fmaxf(m, (float)base[(size_t)((2 * py + dy) * w + 2 * px + dx) * ldin]);
+  out[ot * ldout + c] = (T)m;
+}
+
+// ------------------------------------------------------------------ token re-ordering between window sizes
+__global__ void permute_tokens_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C,
+                                      int w_in, int w_out, const float* __restrict__ up, int w_up) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * H * W * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const size_t ot = i / C;
+  const int b = (int)(ot / ((size_t)H * W));
+  const int t = (int)(ot % ((size_t)H * W));
+  // destination token t (window size w_out) -> (y, x)
+  const int ww = w_out * w_out, wpr = W / w_out;
+  const int win = t / ww, in_w = t % ww;
+  const int y = (win / wpr) * w_out + in_w / w_out, x = (win % wpr) * w_out + in_w % w_out;
+  float v = in[((size_t)b * H * W + tok_of_yx(y, x, W, w_in)) * C + c];
+  if (up) v += up[((size_t)b * (H / 2) * (W / 2) + tok_of_yx(y / 2, x / 2, W / 2, w_up)) * C + c];
+  out[i] = v;
+}
+
+// ------------------------------------------------------------------ batched transpose through LDS
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const float* ib = in + (size_t)b * R * Cc;
+  float* ob = out + (size_t)b * R * Cc;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    if (r < R && c < Cc) tile[j][tx] = ib[(size_t)r * Cc + c];
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (r < R && c < Cc) ob[(size_t)c * R + r] = tile[tx][j];
+  }
+}
+
+__global__ void add_rowvec_kernel(float* x, int ld, const float* __restrict__ v, int M, int C, const float* flag) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * C) return;
+  const float f = flag ? ((flag[0] > 0.f) ? 0.f : 1.f) : 1.f;
+  const int m = (int)(i / C), c = (int)(i % C);
+  x[(size_t)m * ld + c] += f * v[c];
+}
+
+__global__ void round_bf16_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float f = in[i];
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7F800000u) != 0x7F800000u) {           // finite: round to nearest even on bit 16
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    u &= 0xFFFF0000u;
+  }
+  out[i] = __uint_as_float(u);
+}
+
+__global__ void fill_f32_kernel(float* p, float v, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+inline dim3 grid1d(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+}  // namespace
+
+hipError_t layernorm_launch(const float* x, int ldx, const float* w, const float* b, float eps, int M, int C, half_t* y16,
+                            int ldy16, float* y32, int ldy32, int act, hipStream_t s) {
+  layernorm_kernel<<<dim3((M + 3) / 4), dim3(256), 0, s>>>(x, ldx, w, b, eps, M, C, y16, ldy16, y32, ldy32, act);
+  return hipGetLastError();
+}
+hipError_t cast_add_launch(const float* a, int lda, const float* b, int ldb, int bmod, float sb, int M, int C, half_t* y16,
+                           int ldy16, float* y32, int ldy32, hipStream_t s) {
+  cast_add_kernel<<<grid1d((size_t)M * C), dim3(256), 0, s>>>(a, lda, b, ldb, bmod, sb, M, C, y16, ldy16, y32, ldy32);
+  return hipGetLastError();
+}
+hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStream_t s) {
+  const size_t total = (size_t)B * (S / 4) * (S / 4) * 20;
+  im2col_patch_kernel<<<grid1d(total), dim3(256), 0, s>>>(img, B, S, A);
+  return hipGetLastError();
+}
+hipError_t pool_tokens_f32_launch(const float* in, int ldin, float* out, int ldout, int nwin, int w, int C, hipStream_t s) {
+  pool_tokens_kernel<float><<<grid1d((size_t)nwin * (w / 2) * (w / 2) * C), dim3(256), 0, s>>>(in, ldin, out, ldout, nwin, w, C);
+  return hipGetLastError();
+}
+hipError_t pool_tokens_f16_launch(const half_t* in, int ldin, half_t* out, int ldout, int nwin, int w, int C, hipStream_t s) {
+  pool_tokens_kernel<half_t><<<grid1d((size_t)nwin * (w / 2) * (w / 2) * C), dim3(256), 0, s>>>(in, ldin, out, ldout, nwin, w, C);
+  return hipGetLastError();
+}
+hipError_t permute_tokens_launch(const float* in, float* out, int B, int H, int W, int C, int w_in, int w_out,
+                                 const float* up, int w_up, hipStream_t s) {
+  permute_tokens_kernel<<<grid1d((size_t)B * H * W * C), dim3(256), 0, s>>>(in, out, B, H, W, C, w_in, w_out, up, w_up);
+  return hipGetLastError();
+}
+hipError_t transpose_f32_launch(const float* in, float* out, int batch, int R, int Cc, hipStream_t s) {
+  transpose_f32_kernel<<<dim3((Cc + 31) / 32, (R + 31) / 32, batch), dim3(256), 0, s>>>(in, out, R, Cc);
+  return hipGetLastError();
+}
+hipError_t add_rowvec_launch(float* x, int ld, const float* v, int M, int C, const float* flag, hipStream_t s) {
+  add_rowvec_kernel<<<grid1d((size_t)M * C), dim3(256), 0, s>>>(x, ld, v, M, C, flag);
+  return hipGetLastError();
+}
+hipError_t round_bf16_launch(const float* in, float* out, size_t n, hipStream_t s) {
+  round_bf16_kernel<<<grid1d(n), dim3(256), 0, s>>>(in, out, n);
+  return hipGetLastError();
+}
+hipError_t fill_f32_launch(float* p, float v, size_t n, hipStream_t s) {
+  fill_f32_kernel<<<grid1d(n), dim3(256), 0, s>>>(p, v, n);
+  return hipGetLastError();
+}

@@ -1,0 +1,195 @@
+// Internal engine state behind the C ABI (include/sam2mi.h).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/sam2mi.h"
+#include "attn.h"
+#include "gemm.h"
+#include "kernels.h"
+
+struct HostW {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct Lin16 {            // MFMA operand: f16 weight [N, K] (nn.Linear layout), f32 bias
+  half_t* w = nullptr;
+  float* b = nullptr;
+  int N = 0, K = 0;
+};
+struct Lin32 {            // tiny fp32 linear for the token-side heads
+  float* w = nullptr;
+  float* b = nullptr;
+  int N = 0, K = 0;
+};
+struct Norm {
+  float* w = nullptr;
+  float* b = nullptr;
+  int C = 0;
+};
+
+struct HieraBlockW {
+  int idx, dim, dim_out, heads, window;
+  bool q_pool, stage_end;
+  Norm n1, n2;
+  Lin16 qkv, proj, fc1, fc2, sc;   // sc: dim-change shortcut projection (blocks 2, 8, 44)
+};
+
+struct MemAttnLayerW {
+  Norm n1, n2, n3;
+  Lin16 self_qkv;   // [768, 256] = q_proj | k_proj | v_proj
+  Lin16 self_out, cross_q, cross_out, lin1, lin2;
+};
+
+struct AttnW32 { Lin32 q, k, v, o; };          // token-side projections (fp32)
+struct DecLayerW {
+  AttnW32 self_attn;                            // 256 -> 256
+  Lin32 t2i_q, t2i_o;                           // token side of token->image attention
+  Lin16 t2i_k, t2i_v;                           // image side [128, 256]
+  Lin16 i2t_q;                                  // image side query projection [128, 256]
+  Lin32 i2t_k, i2t_v;                           // token side
+  Lin16 i2t_o;                                  // [256, 128]
+  Lin32 mlp1, mlp2;
+  Norm n1, n2, n3, n4;
+};
+
+struct ProfAcc {
+  double ms = 0, flops = 0;
+  int64_t launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+};
+
+struct sam2mi_ctx {
+  sam2mi_config cfg;
+  std::string err;
+  bool finalized = false;
+  std::unordered_map<std::string, HostW> hw;     // host copies until finalize
+  std::vector<void*> allocs;
+
+  // ---- image encoder
+  std::vector<HieraBlockW> blocks;
+  Lin16 patch;                 // [embed, 160] (K padded from 147)
+  float* pos_tab = nullptr;    // [G*G, embed] f32, window-major (w = window_spec[0]) token order
+  Lin16 neck[4];               // index = level (0: stride 4 ... 3: stride 32)
+  Lin16 conv_s0, conv_s1;
+  float* sine_pe[3] = {nullptr, nullptr, nullptr};   // NCHW [256, S, S] for S = 256, 128, 64
+  float* sine_pe_tok64 = nullptr;                    // the 64x64 table token-major [4096, 256]
+  float* no_mem_embed = nullptr;                     // [256]
+  // ---- memory attention
+  std::vector<MemAttnLayerW> mal;
+  Lin16 cross_k_all, cross_v_all;    // [4*256, 64]
+  Norm ma_norm;
+  float* rope_cos = nullptr;         // [4096, 128]
+  float* rope_sin = nullptr;
+  // ---- SAM heads
+  std::vector<DecLayerW> dec;
+  Lin32 fin_q, fin_o;
+  Lin16 fin_k, fin_v;
+  Norm fin_norm;
+  float* out_tokens = nullptr;       // [6, 256] obj_score | iou | 4 mask tokens
+  Lin16 dc1, dc2;                    // ConvTranspose as GEMM: [4*64, 256], [4*32, 64]
+  float* dc1_b = nullptr; float* dc2_b = nullptr;
+  Norm up_ln;
+  Lin32 hyper[4][3], iou_head[3], obj_head[3], ptr_proj[3];
+  Lin32 tpos_proj;                   // obj_ptr_tpos_proj (64, 256)
+  float* no_obj_ptr = nullptr;
+  float* gauss = nullptr;            // [2, 128]
+  float* point_emb4 = nullptr;       // [4, 256]
+  float* not_a_point = nullptr;      // [256]
+  float* no_mask_embed = nullptr;    // [256]
+  float* dense_pe = nullptr;         // [4096, 256] token-major
+  // ---- memory encoder
+  float* md_w[3]; float* md_b[3]; Norm md_ln[4];   // direct convs 1->4, 4->16, 16->64
+  Lin16 md_conv4;                     // [256, 576] (k = (ky*3+kx)*64 + c)
+  Lin16 md_proj, pix_proj, me_out;    // 1x1 convs
+  struct CX { float* dw_w; float* dw_b; Norm ln; Lin16 pw1, pw2; float* gamma; } cx[2];
+  float* mem_pos = nullptr;           // sine PE 64 feats, token-major [4096, 64]
+  float* mem_pos_nchw = nullptr;      // [64, 64, 64]
+  float* tpos_enc = nullptr;          // [7, 64]
+  float* no_obj_embed_spatial = nullptr;   // [64]
+
+  // ---- workspaces (sized for cfg.max_batch frames)
+  float* ws_x = nullptr;        // residual stream f32
+  float* ws_x2 = nullptr;       // second f32 buffer (shortcut / permute target)
+  half_t* ws_a16 = nullptr;     // LN output / generic f16 operand
+  half_t* ws_qk16 = nullptr;    // [M, 2C]
+  half_t* ws_vT16 = nullptr;    // [C, M]
+  half_t* ws_att16 = nullptr;   // [M, C]
+  half_t* ws_h16 = nullptr;     // [M, 4C]
+  half_t* ws_qp16 = nullptr;    // pooled q
+  float* ws_lat[4] = {nullptr, nullptr, nullptr, nullptr};   // neck laterals f32 [M_i, 256]
+  half_t* ws_lat16 = nullptr;   // f16 copy of a lateral (conv_s0 / conv_s1 operand)
+  float* ws_small = nullptr;    // conv_s0 / conv_s1 window-major output
+  size_t ws_tokens = 0;         // max tokens (max_batch * G*G)
+
+  // per-frame (B = 1) tracking workspaces
+  float* t_x = nullptr; half_t* t_h16 = nullptr; half_t* t_qk16 = nullptr; half_t* t_vT16 = nullptr;
+  half_t* t_o16 = nullptr; half_t* t_q16 = nullptr; half_t* t_ff16 = nullptr;
+  half_t* t_kin16 = nullptr; half_t* t_vin16 = nullptr; half_t* t_kall16 = nullptr; half_t* t_vTall16 = nullptr;
+  float* t_opart = nullptr; float* t_ml = nullptr;
+  int t_nk_cap = 0;             // padded key capacity
+  float* t_ptr_tok = nullptr; float* t_ptr_pos = nullptr;
+  float* t_pix = nullptr;       // memory-conditioned features [4096, 256]
+  // decoder
+  float* d_keys = nullptr; half_t* d_keys16 = nullptr; half_t* d_kpe16 = nullptr;
+  float* d_tok = nullptr; float* d_tokpe = nullptr; float* d_t1 = nullptr; float* d_t2 = nullptr; float* d_t3 = nullptr;
+  float* d_t4 = nullptr; float* d_big1 = nullptr; float* d_big2 = nullptr; float* d_big3 = nullptr; half_t* d_big16 = nullptr;
+  float* d_tokens_in = nullptr; float* d_sparse = nullptr;
+  half_t* d_up1_16 = nullptr; half_t* d_up2_16 = nullptr; float* d_g = nullptr;
+  float* d_hyper = nullptr; half_t* d_hyper16 = nullptr;
+  float* d_masks = nullptr; float* d_iou = nullptr; float* d_obj = nullptr; float* d_mtok = nullptr;
+  float* d_low_multi = nullptr; float* d_low_sel = nullptr; float* d_tok_sel = nullptr; int* d_best = nullptr; float* d_iou_sel = nullptr;
+  float* d_ptr = nullptr; float* d_pts = nullptr; int* d_labels = nullptr;
+  // memory encoder
+  float* m_mask = nullptr; float* m_c1 = nullptr; float* m_c2 = nullptr; half_t* m_c3_16 = nullptr; half_t* m_col16 = nullptr;
+  float* m_c4 = nullptr; half_t* m_c4_16 = nullptr; float* m_emb = nullptr; float* m_x = nullptr; float* m_dw = nullptr;
+  half_t* m_ln16 = nullptr; half_t* m_h16 = nullptr; float* m_out = nullptr; half_t* m_pix16 = nullptr;
+  // plug-boundary scratch (layout conversion)
+  float* p_a = nullptr; float* p_b = nullptr; float* p_c = nullptr; float* p_d = nullptr;
+
+  // ---- video state
+  struct FeatSlot { float* feat2; float* fpn1; float* fpn0; };   // token-major row-major
+  std::vector<FeatSlot> feats;
+  struct BankSlot { float* mem; float* obj_ptr; float* obj_score; float* low_mask; };
+  std::vector<BankSlot> bank;
+
+  // ---- profiling
+  bool prof_on = false;
+  ProfAcc prof_gemm, prof_attn;
+};
+
+int sam2mi_set_error(sam2mi_ctx* ctx, const char* what, const char* detail);
+#define CHK(expr)                                                               \
+  do {                                                                          \
+    hipError_t _e = (expr);                                                     \
+    if (_e != hipSuccess) return sam2mi_set_error(ctx, #expr, hipGetErrorString(_e)); \
+  } while (0)
+#define CHKI(expr)                 \
+  do {                             \
+    int _r = (expr);               \
+    if (_r != 0) return _r;        \
+  } while (0)
+
+// engine_core.hip
+void* dalloc(sam2mi_ctx* ctx, size_t bytes);
+int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p);                 // with profiling
+int run_hiera_attn(sam2mi_ctx* ctx, hipStream_t s, const HieraAttnParams& p);
+int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p);
+GemmParams lin_params(const half_t* A, int lda, int M, const Lin16& L);            // bias + W filled, n_split = N
+
+// engine_encoder.hip
+struct EncOut { float* feat2; float* fpn1; float* fpn0; };   // token-major [B, HW, C]
+int encoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, const EncOut* outs /*[B]*/);
+int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& blk, int B, int& H, int& W, int& wcur);
+
+// engine_track.hip
+int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const float* curr_pos, int Nk, int n_rope, float* out32);
+int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* keys_tok, const float* dense_tok, int dense_rows,
+                    const float* pos_tok, const float* tokens, int T, const float* hr0_tok, const float* hr1_tok);
+int memenc_forward(sam2mi_ctx* ctx, hipStream_t s, const float* feat2_tok, const float* mask1024, float* out_tok64);

@@ -1,0 +1,300 @@
+// extern "C" entry points: plug-level (reference tensor layouts) and the fused video path.
+#include "engine.h"
+
+static inline hipStream_t S(void* stream) { return (hipStream_t)stream; }
+
+#define REQUIRE_READY()                                                                     \
+  do {                                                                                      \
+    if (!ctx) return 1;                                                                     \
+    if (!ctx->finalized) return sam2mi_set_error(ctx, __func__, "weights not finalized");   \
+  } while (0)
+
+// ------------------------------------------------------------------ image encoder plugs
+static int encode_to_scratch(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, std::vector<EncOut>& outs) {
+  // results go to feature slots [0, B) of the cache used as scratch when called through the plug API
+  if (B > (int)ctx->feats.size()) return sam2mi_set_error(ctx, "image_encoder", "B exceeds feat_slots");
+  outs.resize(B);
+  for (int b = 0; b < B; ++b) outs[b] = {ctx->feats[b].feat2, ctx->feats[b].fpn1, ctx->feats[b].fpn0};
+  return encoder_forward(ctx, s, img, B, outs.data());
+}
+
+extern "C" int sam2mi_image_encoder(sam2mi_ctx* ctx, void* stream, const float* img, int B, float* const out[7]) {
+  REQUIRE_READY();
+  hipStream_t s = S(stream);
+  std::vector<EncOut> outs;
+  CHKI(encode_to_scratch(ctx, s, img, B, outs));
+  for (int b = 0; b < B; ++b) {
+    if (out[0]) CHK(transpose_f32_launch(outs[b].feat2, out[0] + (size_t)b * 256 * 4096, 1, 4096, 256, s));
+    if (out[6]) CHK(transpose_f32_launch(outs[b].feat2, out[6] + (size_t)b * 256 * 4096, 1, 4096, 256, s));
+    if (out[4]) CHK(transpose_f32_launch(outs[b].fpn0, out[4] + (size_t)b * 32 * 65536, 1, 65536, 32, s));
+    if (out[5]) CHK(transpose_f32_launch(outs[b].fpn1, out[5] + (size_t)b * 64 * 16384, 1, 16384, 64, s));
+    for (int i = 0; i < 3; ++i) {
+      const size_t n = (size_t)256 * (65536 >> (2 * i));
+      if (out[1 + i]) CHK(hipMemcpyAsync(out[1 + i] + b * n, ctx->sine_pe[i], n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+  }
+  return 0;
+}
+
+namespace {
+__global__ void normalize_img_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n_per_chan, int B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * 3 * n_per_chan) return;
+  const int c = (int)((i / n_per_chan) % 3);
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  out[i] = (in[i] - mean[c]) / stdv[c];
+}
+__global__ void bilinear_kernel(const float* __restrict__ in, int C, int Hin, int Win, float* __restrict__ out, int Hout, int Wout) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)C * Hout * Wout) return;
+  const int x = (int)(i % Wout), y = (int)((i / Wout) % Hout), c = (int)(i / ((size_t)Wout * Hout));
+  const float sh = (float)Hin / Hout, sw = (float)Win / Wout;
+  float sy = fmaxf(sh * (y + 0.5f) - 0.5f, 0.f), sx = fmaxf(sw * (x + 0.5f) - 0.5f, 0.f);
+  const int y0 = min((int)sy, Hin - 1), x0 = min((int)sx, Win - 1);
+  const int y1 = min(y0 + 1, Hin - 1), x1 = min(x0 + 1, Win - 1);
+  const float ly = sy - y0, lx = sx - x0;
+  const float* p = in + (size_t)c * Hin * Win;
+  out[i] = (1.f - ly) * ((1.f - lx) * p[y0 * Win + x0] + lx * p[y0 * Win + x1]) +
+           ly * ((1.f - lx) * p[y1 * Win + x0] + lx * p[y1 * Win + x1]);
+}
+}  // namespace
+
+extern "C" int sam2mi_set_image_e2e(sam2mi_ctx* ctx, void* stream, const float* img01, int B, float* feat0, float* feat1, float* feat2) {
+  REQUIRE_READY();
+  hipStream_t s = S(stream);
+  const size_t n = (size_t)ctx->cfg.image_size * ctx->cfg.image_size;
+  if (B > ctx->cfg.max_batch) return sam2mi_set_error(ctx, __func__, "batch exceeds cfg.max_batch");
+  float* norm = ctx->ws_x2;    // [B,3,S,S] fits: ws_x2 holds max_batch * 65536 * 288 floats
+  normalize_img_kernel<<<dim3((unsigned)((B * 3 * n + 255) / 256)), dim3(256), 0, s>>>(img01, norm, n, B);
+  CHK(hipGetLastError());
+  // NOTE: ws_x2 is also used inside the trunk (shortcut buffer) but only after the im2col has consumed the image
+  std::vector<EncOut> outs;
+  CHKI(encode_to_scratch(ctx, s, norm, B, outs));
+  for (int b = 0; b < B; ++b) {
+    CHK(add_rowvec_launch(outs[b].feat2, 256, ctx->no_mem_embed, 4096, 256, nullptr, s));
+    if (feat2) CHK(transpose_f32_launch(outs[b].feat2, feat2 + (size_t)b * 256 * 4096, 1, 4096, 256, s));
+    if (feat0) CHK(transpose_f32_launch(outs[b].fpn0, feat0 + (size_t)b * 32 * 65536, 1, 65536, 32, s));
+    if (feat1) CHK(transpose_f32_launch(outs[b].fpn1, feat1 + (size_t)b * 64 * 16384, 1, 16384, 64, s));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ memory attention plug
+extern "C" int sam2mi_memory_attention(sam2mi_ctx* ctx, void* stream, const float* curr, const float* memory, const float* curr_pos,
+                                       const float* memory_pos, const float* memory_exclude, const float* memory_pos_exclude,
+                                       int L, int P, int N, float* out) {
+  REQUIRE_READY();
+  if (N != 1) return sam2mi_set_error(ctx, __func__, "only N == 1 (one object per call) is implemented");
+  hipStream_t s = S(stream);
+  const int n_rope = L * 4096, Nk = n_rope + P;
+  if (Nk <= 0 || (Nk + 31) / 32 * 32 > ctx->t_nk_cap) return sam2mi_set_error(ctx, __func__, "memory length out of range");
+  // kin = f16(memory + memory_pos), vin = f16(memory); with N == 1 the (L,4096,1,64) tensors are [L*4096, 64] rows
+  CHK(cast_add_launch(memory, 64, memory_pos, 64, 0, 1.f, n_rope, 64, ctx->t_kin16, 64, nullptr, 0, s));
+  CHK(cast_add_launch(memory, 64, nullptr, 0, 0, 0.f, n_rope, 64, ctx->t_vin16, 64, nullptr, 0, s));
+  if (P > 0) {
+    CHK(cast_add_launch(memory_exclude, 64, memory_pos_exclude, 64, 0, 1.f, P, 64, ctx->t_kin16 + (size_t)n_rope * 64, 64, nullptr, 0, s));
+    CHK(cast_add_launch(memory_exclude, 64, nullptr, 0, 0, 0.f, P, 64, ctx->t_vin16 + (size_t)n_rope * 64, 64, nullptr, 0, s));
+  }
+  return memattn_forward(ctx, s, curr, curr_pos, Nk, n_rope, out);
+}
+
+// ------------------------------------------------------------------ mask decoder plug
+extern "C" int sam2mi_mask_decoder(sam2mi_ctx* ctx, void* stream, const float* src, const float* tokens, const float* pos_src,
+                                   const float* hr0, const float* hr1, int N, int T, float* masks, float* iou_pred,
+                                   float* mask_tokens_out, float* object_score_logits) {
+  REQUIRE_READY();
+  hipStream_t s = S(stream);
+  for (int n = 0; n < N; ++n) {
+    // NCHW -> token-major
+    CHK(transpose_f32_launch(src + (size_t)n * 256 * 4096, ctx->p_d, 1, 256, 4096, s));
+    CHK(transpose_f32_launch(pos_src + (size_t)n * 256 * 4096, ctx->d_big3, 1, 256, 4096, s));
+    CHK(transpose_f32_launch(hr0 + (size_t)n * 32 * 65536, ctx->p_a, 1, 32, 65536, s));
+    CHK(transpose_f32_launch(hr1 + (size_t)n * 64 * 16384, ctx->p_c, 1, 64, 16384, s));
+    CHKI(decoder_forward(ctx, s, ctx->p_d, nullptr, 0, ctx->d_big3, tokens + (size_t)n * T * 256, T, ctx->p_a, ctx->p_c));
+    if (masks) CHK(hipMemcpyAsync(masks + (size_t)n * 4 * 65536, ctx->d_masks, (size_t)4 * 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (iou_pred) CHK(hipMemcpyAsync(iou_pred + n * 4, ctx->d_iou, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (mask_tokens_out) CHK(hipMemcpyAsync(mask_tokens_out + (size_t)n * 1024, ctx->d_mtok, 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (object_score_logits) CHK(hipMemcpyAsync(object_score_logits + n, ctx->d_obj, sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ memory encoder plug
+extern "C" int sam2mi_memory_encoder(sam2mi_ctx* ctx, void* stream, const float* pix_feat, const float* masks, int N, float* x, float* pos) {
+  REQUIRE_READY();
+  hipStream_t s = S(stream);
+  for (int n = 0; n < N; ++n) {
+    CHK(transpose_f32_launch(pix_feat + (size_t)n * 256 * 4096, ctx->p_d, 1, 256, 4096, s));
+    CHKI(memenc_forward(ctx, s, ctx->p_d, masks + (size_t)n * 1024 * 1024, ctx->m_out));
+    if (x) CHK(transpose_f32_launch(ctx->m_out, x + (size_t)n * 64 * 4096, 1, 4096, 64, s));
+    if (pos) CHK(hipMemcpyAsync(pos + (size_t)n * 64 * 4096, ctx->mem_pos_nchw, (size_t)64 * 4096 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ prompt encoder plug
+extern "C" int sam2mi_prompt_encoder(sam2mi_ctx* ctx, void* stream, const float* coords, const int32_t* labels, int B, int Np,
+                                     float* sparse, float* dense) {
+  REQUIRE_READY();
+  hipStream_t s = S(stream);
+  for (int b = 0; b < B; ++b) {
+    if (sparse)
+      CHK(point_embed_launch(coords + (size_t)b * Np * 2, (const int*)labels + (size_t)b * Np, Np, ctx->gauss, ctx->point_emb4,
+                             ctx->not_a_point, (float)ctx->cfg.image_size, sparse + (size_t)b * (Np + 1) * 256, s));
+    if (dense) {
+      // no_mask_embed broadcast to (256, 64, 64): fill token-major then transpose
+      CHK(fill_f32_launch(ctx->p_d, 0.f, (size_t)4096 * 256, s));
+      CHK(add_rowvec_launch(ctx->p_d, 256, ctx->no_mask_embed, 4096, 256, nullptr, s));
+      CHK(transpose_f32_launch(ctx->p_d, dense + (size_t)b * 256 * 4096, 1, 4096, 256, s));
+    }
+  }
+  return 0;
+}
+
+extern "C" int sam2mi_dense_pe(sam2mi_ctx* ctx, void* stream, float* out) {
+  REQUIRE_READY();
+  CHK(transpose_f32_launch(ctx->dense_pe, out, 1, 4096, 256, S(stream)));
+  return 0;
+}
+
+extern "C" int sam2mi_resize_bilinear(sam2mi_ctx* ctx, void* stream, const float* in, int C, int Hin, int Win, float* out, int Hout, int Wout) {
+  if (!ctx) return 1;
+  const size_t n = (size_t)C * Hout * Wout;
+  bilinear_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream)>>>(in, C, Hin, Win, out, Hout, Wout);
+  CHK(hipGetLastError());
+  return 0;
+}
+
+// ============================================================================================ fused video path
+extern "C" int sam2mi_video_encode(sam2mi_ctx* ctx, void* stream, const float* frames, int B, const int32_t* feat_slots) {
+  REQUIRE_READY();
+  std::vector<EncOut> outs(B);
+  for (int b = 0; b < B; ++b) {
+    const int sl = feat_slots[b];
+    if (sl < 0 || sl >= (int)ctx->feats.size()) return sam2mi_set_error(ctx, __func__, "feature slot out of range");
+    outs[b] = {ctx->feats[sl].feat2, ctx->feats[sl].fpn1, ctx->feats[sl].fpn0};
+  }
+  return encoder_forward(ctx, S(stream), frames, B, outs.data());
+}
+
+// SAM heads after the decoder: select, obj_ptr; writes bank slot + optional outputs
+static int sam_heads_finish(sam2mi_ctx* ctx, hipStream_t s, int multimask, int bank_slot, const sam2mi_frame_out* out) {
+  sam2mi_ctx::BankSlot& bk = ctx->bank[bank_slot];
+  CHK(select_mask_launch(ctx->d_masks, ctx->d_iou, ctx->d_obj, ctx->d_mtok, multimask, ctx->d_best + 2, 0.05f, 0.98f,
+                         ctx->d_low_multi, bk.low_mask, ctx->d_tok_sel, ctx->d_best, ctx->d_iou_sel, s));
+  // obj_ptr = MLP3(token) gated by the object score (sam2_base_official.py:474-484)
+  CHK(small_linear_launch(ctx->d_tok_sel, 256, ctx->ptr_proj[0].w, ctx->ptr_proj[0].b, ctx->d_t1, 256, nullptr, 0, 1, 256, 256, 2, s));
+  CHK(small_linear_launch(ctx->d_t1, 256, ctx->ptr_proj[1].w, ctx->ptr_proj[1].b, ctx->d_t2, 256, nullptr, 0, 1, 256, 256, 2, s));
+  CHK(small_linear_launch(ctx->d_t2, 256, ctx->ptr_proj[2].w, ctx->ptr_proj[2].b, bk.obj_ptr, 256, nullptr, 0, 1, 256, 256, 0, s));
+  CHK(gate_obj_ptr_launch(bk.obj_ptr, ctx->no_obj_ptr, ctx->d_obj, 256, s));
+  CHK(hipMemcpyAsync(bk.obj_score, ctx->d_obj, sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (out) {
+    const int nm = multimask ? 3 : 1;
+    if (out->low_res_masks) CHK(hipMemcpyAsync(out->low_res_masks, bk.low_mask, 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out->low_res_multimasks) CHK(hipMemcpyAsync(out->low_res_multimasks, ctx->d_low_multi, (size_t)nm * 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out->ious) CHK(hipMemcpyAsync(out->ious, ctx->d_iou_sel, nm * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out->obj_ptr) CHK(hipMemcpyAsync(out->obj_ptr, bk.obj_ptr, 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out->object_score_logits) CHK(hipMemcpyAsync(out->object_score_logits, ctx->d_obj, sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out->best_idx) CHK(hipMemcpyAsync(out->best_idx, ctx->d_best, sizeof(int), hipMemcpyDeviceToDevice, s));
+  }
+  return 0;
+}
+
+static int build_tokens(sam2mi_ctx* ctx, hipStream_t s, const float* coords, const int32_t* labels, int Np, int& T) {
+  // tokens = [obj_score, iou, mask x4] ++ sparse(points + pad)   (mask_decoder.py:186-202)
+  if (Np + 1 + 6 > 64) return sam2mi_set_error(ctx, "build_tokens", "too many points");
+  CHK(hipMemcpyAsync(ctx->d_sparse, ctx->out_tokens, 6 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  const float* pts = nullptr;
+  const int* lab = nullptr;
+  if (Np > 0) {
+    CHK(hipMemcpyAsync(ctx->d_pts, coords, (size_t)Np * 2 * sizeof(float), hipMemcpyDefault, s));
+    CHK(hipMemcpyAsync(ctx->d_labels, labels, (size_t)Np * sizeof(int), hipMemcpyDefault, s));
+    pts = ctx->d_pts;
+    lab = ctx->d_labels;
+  }
+  CHK(point_embed_launch(pts, lab, Np, ctx->gauss, ctx->point_emb4, ctx->not_a_point, (float)ctx->cfg.image_size,
+                         ctx->d_sparse + 6 * 256, s));
+  T = 6 + Np + 1;
+  return 0;
+}
+
+extern "C" int sam2mi_video_click(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int Np,
+                                  int multimask, int bank_slot, const sam2mi_frame_out* out) {
+  REQUIRE_READY();
+  hipStream_t s = S(stream);
+  if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size() || bank_slot < 0 || bank_slot >= (int)ctx->bank.size())
+    return sam2mi_set_error(ctx, __func__, "slot out of range");
+  const sam2mi_ctx::FeatSlot& f = ctx->feats[feat_slot];
+  // pix_feat = feat + no_mem_embed (directly_add_no_mem_embed, sam2_base_official.py:953-957)
+  CHK(cast_add_launch(f.feat2, 256, ctx->no_mem_embed, 256, 1, 1.f, 4096, 256, nullptr, 0, ctx->t_pix, 256, s));
+  int T = 0;
+  CHKI(build_tokens(ctx, s, coords, labels, Np, T));
+  CHKI(decoder_forward(ctx, s, ctx->t_pix, ctx->no_mask_embed, 1, ctx->dense_pe, ctx->d_sparse, T, f.fpn0, f.fpn1));
+  if (out && out->pix_feat) CHK(hipMemcpyAsync(out->pix_feat, ctx->t_pix, (size_t)4096 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return sam_heads_finish(ctx, s, multimask, bank_slot, out);
+}
+
+extern "C" int sam2mi_video_encode_memory(sam2mi_ctx* ctx, void* stream, int feat_slot, int bank_slot, int is_mask_from_pts) {
+  REQUIRE_READY();
+  hipStream_t s = S(stream);
+  if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size() || bank_slot < 0 || bank_slot >= (int)ctx->bank.size())
+    return sam2mi_set_error(ctx, __func__, "slot out of range");
+  sam2mi_ctx::BankSlot& bk = ctx->bank[bank_slot];
+  // mask_for_mem = (binarize ? mask > 0 : sigmoid(mask)) * 20 - 10 on the 1024^2 bilinear upsampling (:1000-1010)
+  CHK(mask_prep_launch(bk.low_mask, ctx->m_mask, is_mask_from_pts ? 1 : 0, 20.f, -10.f, s));
+  CHKI(memenc_forward(ctx, s, ctx->feats[feat_slot].feat2, ctx->m_mask, ctx->m_out));
+  // + (1 - appearing) * no_obj_embed_spatial, then the bf16 rounding of the memory bank
+  CHK(add_rowvec_launch(ctx->m_out, 64, ctx->no_obj_embed_spatial, 4096, 64, bk.obj_score, s));
+  CHK(round_bf16_launch(ctx->m_out, bk.mem, (size_t)4096 * 64, s));
+  return 0;
+}
+
+extern "C" int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, const sam2mi_mem_select* sel, int bank_slot,
+                                  int run_mem_encoder, const sam2mi_frame_out* out) {
+  REQUIRE_READY();
+  hipStream_t s = S(stream);
+  if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size() || bank_slot < 0 || bank_slot >= (int)ctx->bank.size())
+    return sam2mi_set_error(ctx, __func__, "slot out of range");
+  if (!sel || sel->num_mem <= 0 || sel->num_mem > 8 || sel->num_ptr < 0 || sel->num_ptr > 32)
+    return sam2mi_set_error(ctx, __func__, "memory selection out of range (1..8 memories, 0..32 pointers)");
+  const sam2mi_ctx::FeatSlot& f = ctx->feats[feat_slot];
+  const int L = sel->num_mem, P = 4 * sel->num_ptr;
+  // object-pointer tokens + their temporal position encoding
+  if (sel->num_ptr > 0) {
+    PtrTokParams pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.n = sel->num_ptr;
+    for (int i = 0; i < pp.n; ++i) {
+      const int sl = sel->ptr_slot[i];
+      if (sl < 0 || sl >= (int)ctx->bank.size()) return sam2mi_set_error(ctx, __func__, "pointer slot out of range");
+      pp.ptr[i] = ctx->bank[sl].obj_ptr;
+      pp.dt[i] = sel->ptr_dt[i];
+    }
+    pp.tmax = sel->ptr_tmax; pp.Wt = ctx->tpos_proj.w; pp.bt = ctx->tpos_proj.b; pp.tok = ctx->t_ptr_tok; pp.pos = ctx->t_ptr_pos;
+    CHK(ptr_tokens_launch(pp, s));
+  }
+  MemAssembleParams ma;
+  memset(&ma, 0, sizeof(ma));
+  ma.L = L;
+  for (int i = 0; i < L; ++i) {
+    const int sl = sel->mem_slot[i];
+    if (sl < 0 || sl >= (int)ctx->bank.size() || sel->mem_tpos[i] < 0 || sel->mem_tpos[i] >= 7)
+      return sam2mi_set_error(ctx, __func__, "memory slot / tpos out of range");
+    ma.feat[i] = ctx->bank[sl].mem;
+    ma.tpos[i] = ctx->tpos_enc + sel->mem_tpos[i] * 64;
+  }
+  ma.pos = ctx->mem_pos; ma.ptr_tok = ctx->t_ptr_tok; ma.ptr_pos = ctx->t_ptr_pos; ma.P = P;
+  ma.kin = ctx->t_kin16; ma.vin = ctx->t_vin16;
+  CHK(mem_assemble_launch(ma, s));
+  CHKI(memattn_forward(ctx, s, f.feat2, ctx->sine_pe_tok64, L * 4096 + P, L * 4096, ctx->t_pix));
+  if (out && out->pix_feat) CHK(hipMemcpyAsync(out->pix_feat, ctx->t_pix, (size_t)4096 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  int T = 0;
+  CHKI(build_tokens(ctx, s, nullptr, nullptr, 0, T));      // no prompt: one padding point (label -1) + pad
+  // _forward_sam_heads pads with ONE (0,0)/-1 point and the prompt encoder appends another pad point (:395-401, prompt_encoder.py:133-137)
+  CHK(hipMemcpyAsync(ctx->d_sparse + (size_t)T * 256, ctx->d_sparse + (size_t)(T - 1) * 256, 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  T += 1;
+  CHKI(decoder_forward(ctx, s, ctx->t_pix, ctx->no_mask_embed, 1, ctx->dense_pe, ctx->d_sparse, T, f.fpn0, f.fpn1));
+  CHKI(sam_heads_finish(ctx, s, 1, bank_slot, out));
+  if (run_mem_encoder) CHKI(sam2mi_video_encode_memory(ctx, stream, feat_slot, bank_slot, 0));
+  return 0;
+}

@@ -1,0 +1,684 @@
+// Context, weight packing, input-independent tables and profiled launch wrappers.
+#include <cmath>
+#include <cstring>
+
+#include "engine.h"
+
+static std::string g_create_error;
+
+int sam2mi_set_error(sam2mi_ctx* ctx, const char* what, const char* detail) {
+  std::string m = std::string(what) + ": " + detail;
+  if (ctx) ctx->err = m; else g_create_error = m;
+  return 1;
+}
+
+void* dalloc(sam2mi_ctx* ctx, size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0) bytes = 16;
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  hipMemset(p, 0, bytes);     // finite contents everywhere (pad regions are read by MFMA tiles)
+  ctx->allocs.push_back(p);
+  return p;
+}
+
+template <typename T>
+static T* dupload(sam2mi_ctx* ctx, const std::vector<T>& v) {
+  T* p = (T*)dalloc(ctx, v.size() * sizeof(T));
+  if (p && !v.empty()) hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+  return p;
+}
+
+// ------------------------------------------------------------------ profiling wrappers
+static void prof_begin(sam2mi_ctx* ctx, ProfAcc& a, hipStream_t s, hipEvent_t& e0, hipEvent_t& e1) {
+  if (a.pool.empty()) {
+    // drain pending (synchronises; profiling mode only)
+    for (auto& pr : a.pending) {
+      hipEventSynchronize(pr.second);
+      float ms = 0;
+      hipEventElapsedTime(&ms, pr.first, pr.second);
+      a.ms += ms;
+      a.pool.push_back(pr);
+    }
+    a.pending.clear();
+    if (a.pool.empty()) {
+      for (int i = 0; i < 2048; ++i) {
+        hipEvent_t x, y;
+        hipEventCreate(&x);
+        hipEventCreate(&y);
+        a.pool.push_back({x, y});
+      }
+    }
+  }
+  auto pr = a.pool.back();
+  a.pool.pop_back();
+  e0 = pr.first;
+  e1 = pr.second;
+  hipEventRecord(e0, s);
+}
+static void prof_end(ProfAcc& a, hipStream_t s, hipEvent_t e0, hipEvent_t e1, double flops) {
+  hipEventRecord(e1, s);
+  a.pending.push_back({e0, e1});
+  a.flops += flops;
+  a.launches += 1;
+}
+
+int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p) {
+  hipEvent_t e0, e1;
+  if (ctx->prof_on) prof_begin(ctx, ctx->prof_gemm, s, e0, e1);
+  CHK(gemm_launch(p, s));
+  if (ctx->prof_on) prof_end(ctx->prof_gemm, s, e0, e1, 2.0 * p.M * (double)p.N * p.K);
+  return 0;
+}
+int run_hiera_attn(sam2mi_ctx* ctx, hipStream_t s, const HieraAttnParams& p) {
+  hipEvent_t e0, e1;
+  if (ctx->prof_on) prof_begin(ctx, ctx->prof_attn, s, e0, e1);
+  CHK(hiera_attn_launch(p, s));
+  // algorithmic flops: 4 * Nq * Nk_visible * 72 per head
+  const double nk_vis = (p.wq >= p.GQ) ? p.GK : p.wk;
+  if (ctx->prof_on) prof_end(ctx->prof_attn, s, e0, e1, 4.0 * p.num_groups * (double)p.GQ * nk_vis * 72.0 * p.heads);
+  return 0;
+}
+int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p) {
+  hipEvent_t e0, e1;
+  if (ctx->prof_on) prof_begin(ctx, ctx->prof_attn, s, e0, e1);
+  CHK(flash256_launch(p, s));
+  if (ctx->prof_on) prof_end(ctx->prof_attn, s, e0, e1, 4.0 * p.Nq * (double)p.Nk * 256.0);
+  return 0;
+}
+
+GemmParams lin_params(const half_t* A, int lda, int M, const Lin16& L) {
+  GemmParams p = gemm_params_zero();
+  p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.K; p.M = M; p.N = L.N; p.K = L.K; p.bias = L.b; p.n_split = L.N;
+  return p;
+}
+
+// ------------------------------------------------------------------ weight access helpers
+namespace {
+struct Packer {
+  sam2mi_ctx* ctx;
+  bool ok = true;
+  std::string missing;
+  const HostW* get(const std::string& k) {
+    auto it = ctx->hw.find(k);
+    if (it == ctx->hw.end()) {
+      ok = false;
+      if (missing.size() < 400) missing += k + " ";
+      return nullptr;
+    }
+    return &it->second;
+  }
+  float* f32(const std::string& k) {
+    const HostW* w = get(k);
+    return w ? dupload(ctx, w->data) : nullptr;
+  }
+  Norm norm(const std::string& p) {
+    Norm n;
+    const HostW* w = get(p + ".weight");
+    n.w = f32(p + ".weight");
+    n.b = f32(p + ".bias");
+    n.C = w ? (int)w->data.size() : 0;
+    return n;
+  }
+  Lin16 lin16_raw(const std::vector<float>& W, const std::vector<float>& b, int N, int K) {
+    Lin16 l;
+    std::vector<half_t> h((size_t)N * K);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (half_t)W[i];
+    l.w = dupload(ctx, h);
+    l.b = dupload(ctx, b);
+    l.N = N;
+    l.K = K;
+    return l;
+  }
+  // nn.Linear / 1x1 conv: weight (N, K[,1,1])
+  Lin16 lin16(const std::string& p) {
+    const HostW* w = get(p + ".weight");
+    const HostW* b = get(p + ".bias");
+    if (!w || !b) return Lin16();
+    const int N = (int)w->shape[0];
+    const int K = (int)(w->data.size() / N);
+    return lin16_raw(w->data, b->data, N, K);
+  }
+  Lin32 lin32(const std::string& p) {
+    Lin32 l;
+    const HostW* w = get(p + ".weight");
+    if (!w) return l;
+    l.N = (int)w->shape[0];
+    l.K = (int)(w->data.size() / l.N);
+    l.w = f32(p + ".weight");
+    l.b = f32(p + ".bias");
+    return l;
+  }
+  Lin16 concat16(const std::vector<std::string>& ps) {
+    std::vector<float> W, B;
+    int K = 0, N = 0;
+    for (auto& p : ps) {
+      const HostW* w = get(p + ".weight");
+      const HostW* b = get(p + ".bias");
+      if (!w || !b) return Lin16();
+      K = (int)(w->data.size() / w->shape[0]);
+      N += (int)w->shape[0];
+      W.insert(W.end(), w->data.begin(), w->data.end());
+      B.insert(B.end(), b->data.begin(), b->data.end());
+    }
+    return lin16_raw(W, B, N, K);
+  }
+};
+
+inline float cubic1(float x, float A) { return ((A + 2) * x - (A + 3)) * x * x + 1; }
+inline float cubic2(float x, float A) { return ((A * x - 5 * A) * x + 8 * A) * x - 4 * A; }
+
+// F.interpolate(mode="bicubic", align_corners=False) of in [C, Hin, Win] -> out [C, Hout, Wout]
+void bicubic_resize(const float* in, int C, int Hin, int Win, float* out, int Hout, int Wout) {
+  const float A = -0.75f;
+  auto prep = [&](int insz, int outsz, std::vector<int>& idx, std::vector<float>& wt) {
+    idx.resize((size_t)outsz * 4);
+    wt.resize((size_t)outsz * 4);
+    const float scale = (float)insz / (float)outsz;
+    for (int o = 0; o < outsz; ++o) {
+      const float real = scale * (o + 0.5f) - 0.5f;
+      int i0 = (int)std::floor(real);
+      i0 = std::min(i0, insz - 1);
+      float t = std::min(std::max(real - (float)i0, 0.f), 1.f);
+      const float c[4] = {cubic2(t + 1.f, A), cubic1(t, A), cubic1(1.f - t, A), cubic2(2.f - t, A)};
+      for (int j = 0; j < 4; ++j) {
+        idx[o * 4 + j] = std::max(std::min(i0 + j - 1, insz - 1), 0);
+        wt[o * 4 + j] = c[j];
+      }
+    }
+  };
+  std::vector<int> iy, ix;
+  std::vector<float> wy, wx;
+  prep(Hin, Hout, iy, wy);
+  prep(Win, Wout, ix, wx);
+  for (int c = 0; c < C; ++c)
+    for (int y = 0; y < Hout; ++y)
+      for (int x = 0; x < Wout; ++x) {
+        float acc = 0.f;
+        for (int i = 0; i < 4; ++i) {
+          float row = 0.f;
+          for (int j = 0; j < 4; ++j) row += wx[x * 4 + j] * in[((size_t)c * Hin + iy[y * 4 + i]) * Win + ix[x * 4 + j]];
+          acc += wy[y * 4 + i] * row;
+        }
+        out[((size_t)c * Hout + y) * Wout + x] = acc;
+      }
+}
+
+// PositionEmbeddingSine._pe (position_encoding.py:90-125): NCHW [F, H, W], F = num_pos_feats
+std::vector<float> sine_pe_nchw(int H, int W, int F) {
+  const int n = F / 2;
+  std::vector<float> out((size_t)F * H * W);
+  const float two_pi = 2.f * (float)M_PI;
+  std::vector<float> dim_t(n);
+  for (int j = 0; j < n; ++j) dim_t[j] = std::pow(10000.f, 2.f * (float)(j / 2) / (float)n);
+  for (int y = 0; y < H; ++y) {
+    const float ye = (float)(y + 1) / ((float)H + 1e-6f) * two_pi;
+    for (int x = 0; x < W; ++x) {
+      const float xe = (float)(x + 1) / ((float)W + 1e-6f) * two_pi;
+      for (int j = 0; j < n; ++j) {
+        const float py = ye / dim_t[j], px = xe / dim_t[j];
+        out[((size_t)j * H + y) * W + x] = (j & 1) ? std::cos(py) : std::sin(py);
+        out[((size_t)(n + j) * H + y) * W + x] = (j & 1) ? std::cos(px) : std::sin(px);
+      }
+    }
+  }
+  return out;
+}
+}  // namespace
+
+extern "C" int sam2mi_abi_version(void) { return 1; }
+
+extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
+  if (!cfg || !out) return sam2mi_set_error(nullptr, "sam2mi_create", "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return sam2mi_set_error(nullptr, "sam2mi_create", "no HIP device visible (this backend has no CPU fallback)");
+  sam2mi_ctx* ctx = new sam2mi_ctx();
+  ctx->cfg = *cfg;
+  if (ctx->cfg.max_batch <= 0) ctx->cfg.max_batch = 1;
+  if (ctx->cfg.bank_slots <= 0) ctx->cfg.bank_slots = 64;
+  if (ctx->cfg.feat_slots <= 0) ctx->cfg.feat_slots = 16;
+  hipError_t e = gemm_init();
+  if (e != hipSuccess) {
+    sam2mi_set_error(nullptr, "gemm_init", hipGetErrorString(e));
+    delete ctx;
+    return 1;
+  }
+  *out = ctx;
+  return 0;
+}
+
+extern "C" void sam2mi_destroy(sam2mi_ctx* ctx) {
+  if (!ctx) return;
+  hipDeviceSynchronize();
+  for (void* p : ctx->allocs) hipFree(p);
+  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn}) {
+    for (auto& pr : a->pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto& pr : a->pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+  }
+  delete ctx;
+}
+
+extern "C" const char* sam2mi_last_error(sam2mi_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int sam2mi_load_weight(sam2mi_ctx* ctx, const char* key, const float* host_data, const int64_t* shape, int ndim) {
+  if (!ctx || !key || !host_data) return sam2mi_set_error(ctx, "sam2mi_load_weight", "null argument");
+  if (ctx->finalized) return sam2mi_set_error(ctx, "sam2mi_load_weight", "weights already finalized");
+  HostW w;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    w.shape.push_back(shape[i]);
+    n *= (size_t)shape[i];
+  }
+  w.data.assign(host_data, host_data + n);
+  ctx->hw[key] = std::move(w);
+  return 0;
+}
+
+extern "C" int sam2mi_profile_enable(sam2mi_ctx* ctx, int on) {
+  ctx->prof_on = on != 0;
+  if (on) {
+    for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn}) { a->ms = 0; a->flops = 0; a->launches = 0; }
+  }
+  return 0;
+}
+
+extern "C" int sam2mi_profile_read(sam2mi_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches,
+                                   double* attn_ms, double* attn_flops, int64_t* attn_launches) {
+  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn}) {
+    for (auto& pr : a->pending) {
+      hipEventSynchronize(pr.second);
+      float ms = 0;
+      hipEventElapsedTime(&ms, pr.first, pr.second);
+      a->ms += ms;
+      a->pool.push_back(pr);
+    }
+    a->pending.clear();
+  }
+  if (gemm_ms) *gemm_ms = ctx->prof_gemm.ms;
+  if (gemm_flops) *gemm_flops = ctx->prof_gemm.flops;
+  if (gemm_launches) *gemm_launches = ctx->prof_gemm.launches;
+  if (attn_ms) *attn_ms = ctx->prof_attn.ms;
+  if (attn_flops) *attn_flops = ctx->prof_attn.flops;
+  if (attn_launches) *attn_launches = ctx->prof_attn.launches;
+  return 0;
+}
+
+// ------------------------------------------------------------------ finalize: pack everything
+static int alloc_workspaces(sam2mi_ctx* ctx);
+
+extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
+  if (!ctx) return 1;
+  if (ctx->finalized) return 0;
+  const sam2mi_config& c = ctx->cfg;
+  Packer pk{ctx};
+  const int E = c.embed_dim;
+  const int G = c.image_size / 4;
+  if (c.window_spec[0] != 8 || c.window_spec[1] != 4 || c.window_spec[2] != 16 || c.window_spec[3] != 8 || E % 72)
+    return sam2mi_set_error(ctx, "sam2mi_finalize_weights",
+                            "only window_spec (8,4,16,8) with head_dim 72 (hiera-large family) is implemented in the HIP path");
+
+  // ---- Hiera block table (hieradet.py:243-268)
+  {
+    int depth = 0, stage_ends[4], acc = 0;
+    for (int i = 0; i < 4; ++i) { acc += c.stages[i]; stage_ends[i] = acc - 1; }
+    depth = acc;
+    int dim = E, heads = c.num_heads, cur_stage = 1;
+    auto is_end = [&](int i) { for (int k = 0; k < 4; ++k) if (stage_ends[k] == i) return true; return false; };
+    for (int i = 0; i < depth; ++i) {
+      HieraBlockW b;
+      b.idx = i;
+      b.dim = dim;
+      int dim_out = dim;
+      int window = c.window_spec[cur_stage - 1];
+      for (int k = 0; k < 8; ++k) if (c.global_att_blocks[k] == i) window = 0;
+      b.q_pool = false;
+      if (i > 0 && is_end(i - 1)) {
+        dim_out = dim * 2;
+        heads *= 2;
+        cur_stage += 1;
+        b.q_pool = true;
+      }
+      b.dim_out = dim_out;
+      b.heads = heads;
+      b.window = window;
+      b.stage_end = is_end(i);
+      const std::string p = "image_encoder.trunk.blocks." + std::to_string(i) + ".";
+      b.n1 = pk.norm(p + "norm1");
+      b.n2 = pk.norm(p + "norm2");
+      b.qkv = pk.lin16(p + "attn.qkv");
+      b.proj = pk.lin16(p + "attn.proj");
+      b.fc1 = pk.lin16(p + "mlp.layers.0");
+      b.fc2 = pk.lin16(p + "mlp.layers.1");
+      if (dim != dim_out) b.sc = pk.lin16(p + "proj");
+      ctx->blocks.push_back(b);
+      dim = dim_out;
+    }
+  }
+  // ---- patch embed (K 147 -> 160) and the position table in window-major order
+  if (const HostW* w = pk.get("image_encoder.trunk.patch_embed.proj.weight")) {
+    const HostW* b = pk.get("image_encoder.trunk.patch_embed.proj.bias");
+    std::vector<float> W((size_t)E * 160, 0.f);
+    for (int o = 0; o < E; ++o)
+      for (int k = 0; k < 147; ++k) W[(size_t)o * 160 + k] = w->data[(size_t)o * 147 + k];
+    if (b) ctx->patch = pk.lin16_raw(W, b->data, E, 160);
+  }
+  {
+    const HostW* pe = pk.get("image_encoder.trunk.pos_embed");
+    const HostW* pw = pk.get("image_encoder.trunk.pos_embed_window");
+    if (pe && pw) {
+      const int ph = (int)pe->shape[2], pwid = (int)pe->shape[3], ws = (int)pw->shape[2];
+      std::vector<float> big((size_t)E * G * G);
+      bicubic_resize(pe->data.data(), E, ph, pwid, big.data(), G, G);
+      std::vector<float> tab((size_t)G * G * E);
+      for (int y = 0; y < G; ++y)
+        for (int x = 0; x < G; ++x) {
+          const int t = tok_of_yx(y, x, G, 8);
+          for (int ch = 0; ch < E; ++ch)
+            tab[(size_t)t * E + ch] = big[((size_t)ch * G + y) * G + x] + pw->data[((size_t)ch * ws + (y % ws)) * ws + (x % ws)];
+        }
+      ctx->pos_tab = dupload(ctx, tab);
+    }
+  }
+  // ---- neck (image_encoder.py:113-114: convs[n - i] serves level i)
+  for (int lvl = 0; lvl < 4; ++lvl) ctx->neck[lvl] = pk.lin16("image_encoder.neck.convs." + std::to_string(3 - lvl) + ".conv");
+  ctx->conv_s0 = pk.lin16("sam_mask_decoder.conv_s0");
+  ctx->conv_s1 = pk.lin16("sam_mask_decoder.conv_s1");
+  for (int i = 0; i < 3; ++i) {
+    const int S = G >> i;
+    std::vector<float> pe = sine_pe_nchw(S, S, 256);
+    ctx->sine_pe[i] = dupload(ctx, pe);
+    if (i == 2) {
+      std::vector<float> tok((size_t)S * S * 256);
+      for (int ch = 0; ch < 256; ++ch)
+        for (int t = 0; t < S * S; ++t) tok[(size_t)t * 256 + ch] = pe[(size_t)ch * S * S + t];
+      ctx->sine_pe_tok64 = dupload(ctx, tok);
+    }
+  }
+  ctx->no_mem_embed = pk.f32("no_mem_embed");
+
+  // ---- memory attention
+  {
+    std::vector<std::string> ks, vs;
+    for (int l = 0; l < 4; ++l) {
+      const std::string p = "memory_attention.layers." + std::to_string(l) + ".";
+      MemAttnLayerW m;
+      m.n1 = pk.norm(p + "norm1");
+      m.n2 = pk.norm(p + "norm2");
+      m.n3 = pk.norm(p + "norm3");
+      m.self_qkv = pk.concat16({p + "self_attn.q_proj", p + "self_attn.k_proj", p + "self_attn.v_proj"});
+      m.self_out = pk.lin16(p + "self_attn.out_proj");
+      m.cross_q = pk.lin16(p + "cross_attn_image.q_proj");
+      m.cross_out = pk.lin16(p + "cross_attn_image.out_proj");
+      m.lin1 = pk.lin16(p + "linear1");
+      m.lin2 = pk.lin16(p + "linear2");
+      ctx->mal.push_back(m);
+      ks.push_back(p + "cross_attn_image.k_proj");
+      vs.push_back(p + "cross_attn_image.v_proj");
+    }
+    ctx->cross_k_all = pk.concat16(ks);
+    ctx->cross_v_all = pk.concat16(vs);
+    ctx->ma_norm = pk.norm("memory_attention.norm");
+    // axial RoPE table (position_encoding_fix.py:172-205): pair p<64 -> x * theta^(-4p/256), else y * ...
+    std::vector<float> rc((size_t)4096 * 128), rs((size_t)4096 * 128);
+    for (int t = 0; t < 4096; ++t) {
+      const float tx = (float)(t % 64), ty = (float)(t / 64);
+      for (int p = 0; p < 128; ++p) {
+        const int fi = 2 * (p % 64);                       // index into freqs (step 2 of the [..., ::2] slice)
+        const float freq = 1.0f / std::pow(10000.f, (float)(2 * fi) / 256.f);
+        const float ang = (p < 64 ? tx : ty) * freq;
+        rc[(size_t)t * 128 + p] = std::cos(ang);
+        rs[(size_t)t * 128 + p] = std::sin(ang);
+      }
+    }
+    ctx->rope_cos = dupload(ctx, rc);
+    ctx->rope_sin = dupload(ctx, rs);
+  }
+
+  // ---- SAM heads
+  {
+    const std::string d = "sam_mask_decoder.";
+    for (int l = 0; l < 2; ++l) {
+      const std::string p = d + "transformer.layers." + std::to_string(l) + ".";
+      DecLayerW L;
+      L.self_attn = {pk.lin32(p + "self_attn.q_proj"), pk.lin32(p + "self_attn.k_proj"), pk.lin32(p + "self_attn.v_proj"),
+                     pk.lin32(p + "self_attn.out_proj")};
+      L.t2i_q = pk.lin32(p + "cross_attn_token_to_image.q_proj");
+      L.t2i_k = pk.lin16(p + "cross_attn_token_to_image.k_proj");
+      L.t2i_v = pk.lin16(p + "cross_attn_token_to_image.v_proj");
+      L.t2i_o = pk.lin32(p + "cross_attn_token_to_image.out_proj");
+      L.i2t_q = pk.lin16(p + "cross_attn_image_to_token.q_proj");
+      L.i2t_k = pk.lin32(p + "cross_attn_image_to_token.k_proj");
+      L.i2t_v = pk.lin32(p + "cross_attn_image_to_token.v_proj");
+      L.i2t_o = pk.lin16(p + "cross_attn_image_to_token.out_proj");
+      L.mlp1 = pk.lin32(p + "mlp.layers.0");
+      L.mlp2 = pk.lin32(p + "mlp.layers.1");
+      L.n1 = pk.norm(p + "norm1");
+      L.n2 = pk.norm(p + "norm2");
+      L.n3 = pk.norm(p + "norm3");
+      L.n4 = pk.norm(p + "norm4");
+      ctx->dec.push_back(L);
+    }
+    const std::string f = d + "transformer.final_attn_token_to_image.";
+    ctx->fin_q = pk.lin32(f + "q_proj");
+    ctx->fin_k = pk.lin16(f + "k_proj");
+    ctx->fin_v = pk.lin16(f + "v_proj");
+    ctx->fin_o = pk.lin32(f + "out_proj");
+    ctx->fin_norm = pk.norm(d + "transformer.norm_final_attn");
+    {
+      const HostW* a = pk.get(d + "obj_score_token.weight");
+      const HostW* b = pk.get(d + "iou_token.weight");
+      const HostW* m = pk.get(d + "mask_tokens.weight");
+      if (a && b && m) {
+        std::vector<float> t;
+        t.insert(t.end(), a->data.begin(), a->data.end());
+        t.insert(t.end(), b->data.begin(), b->data.end());
+        t.insert(t.end(), m->data.begin(), m->data.end());
+        ctx->out_tokens = dupload(ctx, t);
+      }
+    }
+    // ConvTranspose2d(k=2, s=2) as a GEMM: Wg[(dy*2+dx)*O + o][i] = W[i][o][dy][dx]
+    auto convT = [&](const std::string& key, Lin16& out, float*& bias) {
+      const HostW* w = pk.get(key + ".weight");
+      const HostW* b = pk.get(key + ".bias");
+      if (!w || !b) return;
+      const int I = (int)w->shape[0], O = (int)w->shape[1];
+      std::vector<float> Wg((size_t)4 * O * I), zero((size_t)4 * O, 0.f);
+      for (int i = 0; i < I; ++i)
+        for (int o = 0; o < O; ++o)
+          for (int pos = 0; pos < 4; ++pos) Wg[((size_t)pos * O + o) * I + i] = w->data[((size_t)i * O + o) * 4 + pos];
+      out = pk.lin16_raw(Wg, zero, 4 * O, I);
+      bias = dupload(ctx, b->data);
+    };
+    convT(d + "output_upscaling.0", ctx->dc1, ctx->dc1_b);
+    convT(d + "output_upscaling.3", ctx->dc2, ctx->dc2_b);
+    ctx->up_ln = pk.norm(d + "output_upscaling.1");
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 3; ++j)
+        ctx->hyper[i][j] = pk.lin32(d + "output_hypernetworks_mlps." + std::to_string(i) + ".layers." + std::to_string(j));
+    for (int j = 0; j < 3; ++j) {
+      ctx->iou_head[j] = pk.lin32(d + "iou_prediction_head.layers." + std::to_string(j));
+      ctx->obj_head[j] = pk.lin32(d + "pred_obj_score_head.layers." + std::to_string(j));
+      ctx->ptr_proj[j] = pk.lin32("obj_ptr_proj.layers." + std::to_string(j));
+    }
+    ctx->tpos_proj = pk.lin32("obj_ptr_tpos_proj");
+    ctx->no_obj_ptr = pk.f32("no_obj_ptr");
+    const std::string pe = "sam_prompt_encoder.";
+    ctx->gauss = pk.f32(pe + "pe_layer.positional_encoding_gaussian_matrix");
+    {
+      std::vector<float> t;
+      bool all = true;
+      for (int i = 0; i < 4; ++i) {
+        const HostW* w = pk.get(pe + "point_embeddings." + std::to_string(i) + ".weight");
+        if (!w) { all = false; break; }
+        t.insert(t.end(), w->data.begin(), w->data.end());
+      }
+      if (all) ctx->point_emb4 = dupload(ctx, t);
+    }
+    ctx->not_a_point = pk.f32(pe + "not_a_point_embed.weight");
+    ctx->no_mask_embed = pk.f32(pe + "no_mask_embed.weight");
+  }
+
+  // ---- memory encoder
+  {
+    const std::string m = "memory_encoder.";
+    for (int i = 0; i < 3; ++i) {
+      ctx->md_w[i] = pk.f32(m + "mask_downsampler.encoder." + std::to_string(3 * i) + ".weight");
+      ctx->md_b[i] = pk.f32(m + "mask_downsampler.encoder." + std::to_string(3 * i) + ".bias");
+    }
+    for (int i = 0; i < 4; ++i) ctx->md_ln[i] = pk.norm(m + "mask_downsampler.encoder." + std::to_string(3 * i + 1));
+    if (const HostW* w = pk.get(m + "mask_downsampler.encoder.9.weight")) {
+      const HostW* b = pk.get(m + "mask_downsampler.encoder.9.bias");
+      const int O = (int)w->shape[0], I = (int)w->shape[1];
+      std::vector<float> Wg((size_t)O * 9 * I);
+      for (int o = 0; o < O; ++o)
+        for (int i = 0; i < I; ++i)
+          for (int t = 0; t < 9; ++t) Wg[((size_t)o * 9 + t) * I + i] = w->data[((size_t)o * I + i) * 9 + t];
+      if (b) ctx->md_conv4 = pk.lin16_raw(Wg, b->data, O, 9 * I);
+    }
+    ctx->md_proj = pk.lin16(m + "mask_downsampler.encoder.12");
+    ctx->pix_proj = pk.lin16(m + "pix_feat_proj");
+    ctx->me_out = pk.lin16(m + "out_proj");
+    for (int l = 0; l < 2; ++l) {
+      const std::string p = m + "fuser.layers." + std::to_string(l) + ".";
+      ctx->cx[l].dw_w = pk.f32(p + "dwconv.weight");
+      ctx->cx[l].dw_b = pk.f32(p + "dwconv.bias");
+      ctx->cx[l].ln = pk.norm(p + "norm");
+      ctx->cx[l].pw1 = pk.lin16(p + "pwconv1");
+      ctx->cx[l].pw2 = pk.lin16(p + "pwconv2");
+      ctx->cx[l].gamma = pk.f32(p + "gamma");
+    }
+    std::vector<float> pe = sine_pe_nchw(64, 64, 64);
+    ctx->mem_pos_nchw = dupload(ctx, pe);
+    std::vector<float> tok((size_t)4096 * 64);
+    for (int ch = 0; ch < 64; ++ch)
+      for (int t = 0; t < 4096; ++t) tok[(size_t)t * 64 + ch] = pe[(size_t)ch * 4096 + t];
+    ctx->mem_pos = dupload(ctx, tok);
+    ctx->tpos_enc = pk.f32("maskmem_tpos_enc");
+    ctx->no_obj_embed_spatial = pk.f32("no_obj_embed_spatial");
+  }
+
+  if (!pk.ok) return sam2mi_set_error(ctx, "sam2mi_finalize_weights: missing state_dict keys", pk.missing.c_str());
+  if (hipDeviceSynchronize() != hipSuccess) return sam2mi_set_error(ctx, "sam2mi_finalize_weights", "device error while uploading");
+  CHKI(alloc_workspaces(ctx));
+  // dense positional encoding of the prompt encoder (constant)
+  CHK(dense_pe_launch(ctx->gauss, 64, ctx->dense_pe, 0));
+  CHK(hipDeviceSynchronize());
+  ctx->hw.clear();
+  ctx->finalized = true;
+  return 0;
+}
+
+static int alloc_workspaces(sam2mi_ctx* ctx) {
+  const sam2mi_config& c = ctx->cfg;
+  const int G = c.image_size / 4;
+  const int E = c.embed_dim;
+  const size_t T0 = (size_t)c.max_batch * G * G;      // stage-1 tokens
+  ctx->ws_tokens = T0;
+  // per-token element counts are maximal in stage 1 (tokens / 4 and channels * 2 per stage)
+#define ALLOC(ptr, type, count)                                                     \
+  do {                                                                              \
+    ptr = (type*)dalloc(ctx, (size_t)(count) * sizeof(type));                       \
+    if (!ptr) return sam2mi_set_error(ctx, "hipMalloc", #ptr);                      \
+  } while (0)
+  ALLOC(ctx->ws_x, float, T0 * E);
+  ALLOC(ctx->ws_x2, float, T0 * 2 * E);              // shortcut projection output (unpooled, 2C)
+  ALLOC(ctx->ws_a16, half_t, T0 * 160);              // LN output (<= 144 ch) or im2col patches (160)
+  ALLOC(ctx->ws_qk16, half_t, T0 * 4 * E);           // [M, 2*Cout], Cout up to 2E at stage-1 tokens (block 2)
+  ALLOC(ctx->ws_vT16, half_t, T0 * 2 * E);
+  ALLOC(ctx->ws_att16, half_t, T0 * E);
+  ALLOC(ctx->ws_h16, half_t, T0 * 4 * E);
+  ALLOC(ctx->ws_qp16, half_t, T0 / 4 * 2 * E);
+  for (int l = 0; l < 4; ++l) ALLOC(ctx->ws_lat[l], float, (T0 >> (2 * l)) * 256);
+  ALLOC(ctx->ws_lat16, half_t, T0 * 256);
+  ALLOC(ctx->ws_small, float, T0 * 64);
+
+  // tracking (B = 1)
+  const int NKCAP = 7 * 4096 + 64 * 4 + 4096;         // generous: many conditioning frames are rejected above this
+  ctx->t_nk_cap = NKCAP;
+  ALLOC(ctx->t_x, float, 4096 * 256);
+  ALLOC(ctx->t_h16, half_t, 4096 * 256);
+  ALLOC(ctx->t_qk16, half_t, 4096 * 512);
+  ALLOC(ctx->t_vT16, half_t, 256 * 4096);
+  ALLOC(ctx->t_o16, half_t, 4096 * 256);
+  ALLOC(ctx->t_q16, half_t, 4096 * 256);
+  ALLOC(ctx->t_ff16, half_t, 4096 * 2048);
+  ALLOC(ctx->t_kin16, half_t, (size_t)NKCAP * 64);
+  ALLOC(ctx->t_vin16, half_t, (size_t)NKCAP * 64);
+  ALLOC(ctx->t_kall16, half_t, (size_t)NKCAP * 1024);
+  ALLOC(ctx->t_vTall16, half_t, (size_t)1024 * NKCAP);
+  ALLOC(ctx->t_opart, float, (size_t)16 * 4096 * 256);
+  ALLOC(ctx->t_ml, float, (size_t)16 * 4096 * 2);
+  ALLOC(ctx->t_ptr_tok, float, 128 * 64);
+  ALLOC(ctx->t_ptr_pos, float, 128 * 64);
+  ALLOC(ctx->t_pix, float, 4096 * 256);
+  // decoder
+  ALLOC(ctx->d_keys, float, 4096 * 256);
+  ALLOC(ctx->d_keys16, half_t, 4096 * 256);
+  ALLOC(ctx->d_kpe16, half_t, 4096 * 256);
+  ALLOC(ctx->d_tok, float, 64 * 256);
+  ALLOC(ctx->d_tokpe, float, 64 * 256);
+  ALLOC(ctx->d_t1, float, 64 * 2048);
+  ALLOC(ctx->d_t2, float, 64 * 2048);
+  ALLOC(ctx->d_t3, float, 64 * 2048);
+  ALLOC(ctx->d_t4, float, 64 * 2048);
+  ALLOC(ctx->d_big1, float, 4096 * 256);
+  ALLOC(ctx->d_big2, float, 4096 * 256);
+  ALLOC(ctx->d_big3, float, 4096 * 256);
+  ALLOC(ctx->d_big16, half_t, 4096 * 256);
+  ALLOC(ctx->d_tokens_in, float, 64 * 256);
+  ALLOC(ctx->d_sparse, float, 64 * 256);
+  ALLOC(ctx->d_up1_16, half_t, 16384 * 64);
+  ALLOC(ctx->d_up2_16, half_t, 65536 * 32);
+  ALLOC(ctx->d_g, float, 16384 * 128);
+  ALLOC(ctx->d_hyper, float, 4 * 32);
+  ALLOC(ctx->d_hyper16, half_t, 8 * 32);
+  ALLOC(ctx->d_masks, float, 4 * 65536);
+  ALLOC(ctx->d_iou, float, 8);
+  ALLOC(ctx->d_obj, float, 8);
+  ALLOC(ctx->d_mtok, float, 4 * 256);
+  ALLOC(ctx->d_low_multi, float, 3 * 65536);
+  ALLOC(ctx->d_low_sel, float, 65536);
+  ALLOC(ctx->d_tok_sel, float, 256);
+  ALLOC(ctx->d_best, int, 4);
+  ALLOC(ctx->d_iou_sel, float, 4);
+  ALLOC(ctx->d_ptr, float, 256);
+  ALLOC(ctx->d_pts, float, 64 * 2);
+  ALLOC(ctx->d_labels, int, 64);
+  ALLOC(ctx->dense_pe, float, 4096 * 256);
+  // memory encoder
+  ALLOC(ctx->m_mask, float, 1024 * 1024);
+  ALLOC(ctx->m_c1, float, 512 * 512 * 4);
+  ALLOC(ctx->m_c2, float, 256 * 256 * 16);
+  ALLOC(ctx->m_c3_16, half_t, 128 * 128 * 64);
+  ALLOC(ctx->m_col16, half_t, 4096 * 576);
+  ALLOC(ctx->m_c4, float, 4096 * 256);
+  ALLOC(ctx->m_c4_16, half_t, 4096 * 256);
+  ALLOC(ctx->m_emb, float, 4096 * 256);
+  ALLOC(ctx->m_x, float, 4096 * 256);
+  ALLOC(ctx->m_dw, float, 4096 * 256);
+  ALLOC(ctx->m_ln16, half_t, 4096 * 256);
+  ALLOC(ctx->m_h16, half_t, 4096 * 1024);
+  ALLOC(ctx->m_out, float, 4096 * 64);
+  ALLOC(ctx->m_pix16, half_t, 4096 * 256);
+  // plug scratch
+  ALLOC(ctx->p_a, float, (size_t)65536 * 32);
+  ALLOC(ctx->p_b, float, (size_t)65536 * 32);
+  ALLOC(ctx->p_c, float, (size_t)16384 * 64);
+  ALLOC(ctx->p_d, float, (size_t)4096 * 256);
+  // video caches
+  ctx->feats.resize(c.feat_slots);
+  for (auto& f : ctx->feats) {
+    ALLOC(f.feat2, float, 4096 * 256);
+    ALLOC(f.fpn1, float, 16384 * 64);
+    ALLOC(f.fpn0, float, 65536 * 32);
+  }
+  ctx->bank.resize(c.bank_slots);
+  for (auto& b : ctx->bank) {
+    ALLOC(b.mem, float, 4096 * 64);
+    ALLOC(b.obj_ptr, float, 256);
+    ALLOC(b.obj_score, float, 4);
+    ALLOC(b.low_mask, float, 65536);
+  }
+#undef ALLOC
+  return 0;
+}

@@ -1,0 +1,137 @@
+// Single-kernel entry points behind the C ABI, used by the GPU parity tests (tests/test_kernels_gpu.py).
+#include "engine.h"
+
+namespace {
+struct Tmp {
+  std::vector<void*> ptrs;
+  ~Tmp() { for (void* p : ptrs) hipFree(p); }
+  template <typename T> T* get(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(n, 4) * sizeof(T)) != hipSuccess) return nullptr;
+    hipMemset(p, 0, std::max<size_t>(n, 4) * sizeof(T));
+    ptrs.push_back(p);
+    return (T*)p;
+  }
+};
+__global__ void transpose_to_f16_kernel(const float* __restrict__ in, half_t* __restrict__ out, int R, int Cc, int ldo) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)R * Cc) return;
+  const int r = (int)(i / Cc), c = (int)(i % Cc);
+  out[(size_t)c * ldo + r] = (half_t)in[i];
+}
+__global__ void f16_to_f32_kernel(const half_t* __restrict__ in, float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i];
+}
+}  // namespace
+
+extern "C" int sam2mi_debug_gemm(sam2mi_ctx* ctx, void* stream, const float* A, const float* W, const float* bias, int M, int N, int K,
+                                 int act, const float* residual, float* out) {
+  if (!ctx) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  Tmp t;
+  half_t* a16 = t.get<half_t>((size_t)M * K);
+  half_t* w16 = t.get<half_t>((size_t)N * K);
+  if (!a16 || !w16) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+  CHK(cast_add_launch(A, K, nullptr, 0, 0, 0.f, M, K, a16, K, nullptr, 0, s));
+  CHK(cast_add_launch(W, K, nullptr, 0, 0, 0.f, N, K, w16, K, nullptr, 0, s));
+  GemmParams p = gemm_params_zero();
+  p.A = a16; p.lda = K; p.W = w16; p.ldw = K; p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act; p.n_split = N;
+  p.res = residual; p.ldres = N; p.out32 = out; p.ld32 = N;
+  CHKI(run_gemm(ctx, s, p));
+  CHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+// q [groups*GQ, heads*72], k/v [groups*GK, heads*72] f32 -> out [groups*GQ, heads*72] f32
+extern "C" int sam2mi_debug_hiera_attention(sam2mi_ctx* ctx, void* stream, const float* q, const float* k, const float* v, int groups,
+                                            int heads, int GQ, int GK, int wq, int wk, float* out) {
+  if (!ctx) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  const int C = heads * 72, Mq = groups * GQ, Mk = groups * GK;
+  Tmp t;
+  half_t* q16 = t.get<half_t>((size_t)Mq * C);
+  half_t* k16 = t.get<half_t>((size_t)Mk * C);
+  half_t* vT = t.get<half_t>((size_t)C * Mk);
+  half_t* o16 = t.get<half_t>((size_t)Mq * C);
+  if (!q16 || !k16 || !vT || !o16) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+  CHK(cast_add_launch(q, C, nullptr, 0, 0, 0.f, Mq, C, q16, C, nullptr, 0, s));
+  CHK(cast_add_launch(k, C, nullptr, 0, 0, 0.f, Mk, C, k16, C, nullptr, 0, s));
+  transpose_to_f16_kernel<<<dim3((unsigned)(((size_t)Mk * C + 255) / 256)), dim3(256), 0, s>>>(v, vT, Mk, C, Mk);
+  CHK(hipGetLastError());
+  HieraAttnParams a;
+  memset(&a, 0, sizeof(a));
+  a.q = q16; a.ldq = C; a.k = k16; a.ldk = C; a.vT = vT; a.ldvT = Mk; a.o = o16; a.ldo = C; a.heads = heads;
+  a.GQ = GQ; a.GK = GK; a.wq = wq; a.wk = wk; a.num_groups = groups; a.scale_log2e = 1.4426950408889634f / sqrtf(72.f);
+  CHKI(run_hiera_attn(ctx, s, a));
+  f16_to_f32_kernel<<<dim3((unsigned)(((size_t)Mq * C + 255) / 256)), dim3(256), 0, s>>>(o16, out, (size_t)Mq * C);
+  CHK(hipGetLastError());
+  CHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+// q [Nq,256], k/v [Nk,256] f32 (RoPE already applied by the caller) -> out [Nq,256] f32
+extern "C" int sam2mi_debug_flash256(sam2mi_ctx* ctx, void* stream, const float* q, const float* k, const float* v, int Nq, int Nk, float* out) {
+  if (!ctx) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  const int NkP = (Nk + 31) / 32 * 32;
+  Tmp t;
+  half_t* q16 = t.get<half_t>((size_t)Nq * 256);
+  half_t* k16 = t.get<half_t>((size_t)NkP * 256);
+  half_t* vT = t.get<half_t>((size_t)256 * NkP);
+  half_t* o16 = t.get<half_t>((size_t)Nq * 256);
+  const int splits = std::max(1, std::min(16, ((Nk + 31) / 32) / 16));
+  float* opart = t.get<float>((size_t)splits * Nq * 256);
+  float* ml = t.get<float>((size_t)splits * Nq * 2);
+  if (!q16 || !k16 || !vT || !o16 || !opart || !ml) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+  CHK(cast_add_launch(q, 256, nullptr, 0, 0, 0.f, Nq, 256, q16, 256, nullptr, 0, s));
+  CHK(cast_add_launch(k, 256, nullptr, 0, 0, 0.f, Nk, 256, k16, 256, nullptr, 0, s));
+  transpose_to_f16_kernel<<<dim3((unsigned)(((size_t)Nk * 256 + 255) / 256)), dim3(256), 0, s>>>(v, vT, Nk, 256, NkP);
+  CHK(hipGetLastError());
+  Flash256Params f;
+  memset(&f, 0, sizeof(f));
+  f.q = q16; f.ldq = 256; f.k = k16; f.ldk = 256; f.vT = vT; f.ldvT = NkP; f.Nq = Nq; f.Nk = Nk; f.splits = splits;
+  f.o_part = opart; f.ml_part = ml; f.out = o16; f.ldout = 256; f.scale_log2e = 1.4426950408889634f / 16.f;
+  CHKI(run_flash256(ctx, s, f));
+  f16_to_f32_kernel<<<dim3((unsigned)(((size_t)Nq * 256 + 255) / 256)), dim3(256), 0, s>>>(o16, out, (size_t)Nq * 256);
+  CHK(hipGetLastError());
+  CHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+// One Hiera block on x [B, H, W, C] (row-major NHWC, H = W = the grid of that block's stage) -> out NHWC
+extern "C" int sam2mi_debug_hiera_block(sam2mi_ctx* ctx, void* stream, int block_idx, const float* x_nhwc, int B, float* out_nhwc) {
+  if (!ctx || !ctx->finalized) return sam2mi_set_error(ctx, __func__, "weights not finalized");
+  if (block_idx < 0 || block_idx >= (int)ctx->blocks.size()) return sam2mi_set_error(ctx, __func__, "bad block index");
+  hipStream_t s = (hipStream_t)stream;
+  const HieraBlockW& b = ctx->blocks[block_idx];
+  int G = ctx->cfg.image_size / 4;
+  for (int i = 0; i < block_idx; ++i) if (ctx->blocks[i].q_pool) G /= 2;
+  int H = G, W = G;
+  int w = b.window > 0 ? b.window : 16;
+  if (B > ctx->cfg.max_batch) return sam2mi_set_error(ctx, __func__, "batch exceeds max_batch");
+  CHK(permute_tokens_launch(x_nhwc, ctx->ws_x, B, H, W, b.dim, W, w, nullptr, 0, s));
+  CHKI(hiera_block_forward(ctx, s, b, B, H, W, w));
+  CHK(permute_tokens_launch(ctx->ws_x, out_nhwc, B, H, W, b.dim_out, w, W, nullptr, 0, s));
+  CHK(hipStreamSynchronize(s));
+  return 0;
+}
+
+// copy a named internal buffer (tests only)
+extern "C" int sam2mi_debug_read(sam2mi_ctx* ctx, void* stream, const char* name, float* out, int64_t count) {
+  if (!ctx) return 1;
+  const std::string n(name);
+  const float* src = nullptr;
+  if (n == "d_tok") src = ctx->d_tok;
+  else if (n == "d_keys") src = ctx->d_keys;
+  else if (n == "d_t1") src = ctx->d_t1;
+  else if (n == "d_t2") src = ctx->d_t2;
+  else if (n == "d_big1") src = ctx->d_big1;
+  else if (n == "d_big2") src = ctx->d_big2;
+  else if (n == "t_pix") src = ctx->t_pix;
+  else if (n == "m_out") src = ctx->m_out;
+  else return sam2mi_set_error(ctx, __func__, "unknown buffer");
+  CHK(hipMemcpyAsync(out, src, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  CHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}

@@ -1,0 +1,167 @@
+// Image encoder orchestration: Hiera trunk + FPN neck + conv_s0/conv_s1.
+// Reference: SAM2Base.inference_image_torch (modeling/sam2_base_official.py:566-582),
+// Hiera.forward (modeling/backbones/hieradet.py:283-299), MultiScaleBlock.forward (:134-166),
+// FpnNeck.forward (modeling/backbones/image_encoder.py:102-134).
+//
+// Layout: the residual stream is kept in WINDOW-MAJOR token order inside each stage (all tokens of a
+// window are contiguous rows), so window partition/unpartition (backbones/utils.py:16-60) cost nothing:
+// attention has no positional bias, so any consistent token permutation inside a stage is exact.
+// Q-pooling halves the window edge (8->4 matches stage 2, 16->8 matches stage 4); only the
+// stage-2 -> stage-3 transition (2 -> 16) needs one explicit re-ordering.
+#include "engine.h"
+
+static const float LOG2E = 1.4426950408889634f;
+
+int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, int B, int& H, int& W, int& wcur) {
+  const int M = B * H * W;
+  const int C = b.dim, Co = b.dim_out;
+  float* x = ctx->ws_x;
+  // 1. LN1
+  CHK(layernorm_launch(x, C, b.n1.w, b.n1.b, 1e-6f, M, C, ctx->ws_a16, C, nullptr, 0, 0, s));
+  int Mq = M;
+  float* xres = x;           // residual target of the attention projection
+  if (b.q_pool) {
+    // shortcut = maxpool2x2(proj(LN(x)))   (hieradet.py:139-140)
+    GemmParams p = lin_params(ctx->ws_a16, C, M, b.sc);
+    p.out32 = ctx->ws_x2; p.ld32 = Co;
+    CHKI(run_gemm(ctx, s, p));
+    Mq = M / 4;
+    CHK(pool_tokens_f32_launch(ctx->ws_x2, Co, x, Co, M / (wcur * wcur), wcur, Co, s));   // x is re-used: LN already consumed it
+  }
+  // 2. QKV projection: q|k row-major, v transposed (attention consumes V^T tiles)
+  {
+    GemmParams p = lin_params(ctx->ws_a16, C, M, b.qkv);
+    p.n_split = 2 * Co;
+    p.out16 = ctx->ws_qk16; p.ld16 = 2 * Co;
+    p.outT16 = ctx->ws_vT16; p.ldT16 = M;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  // 3. attention
+  HieraAttnParams a;
+  memset(&a, 0, sizeof(a));
+  a.k = ctx->ws_qk16 + Co; a.ldk = 2 * Co;
+  a.vT = ctx->ws_vT16; a.ldvT = M;
+  a.o = ctx->ws_att16; a.ldo = Co;
+  a.heads = b.heads;
+  a.scale_log2e = LOG2E / sqrtf(72.f);
+  const int win = (b.window > 0) ? wcur : 0;
+  if (!b.q_pool) {
+    a.q = ctx->ws_qk16; a.ldq = 2 * Co;
+    if (win == 0) { a.GQ = a.GK = H * W; a.wq = a.GQ; a.wk = a.GK; a.num_groups = B; }
+    else {
+      const int n = win * win;
+      if (n >= 32) { a.GQ = a.GK = n; a.wq = a.wk = n; a.num_groups = M / n; }
+      else { a.GQ = a.GK = 32; a.wq = a.wk = n; a.num_groups = M / 32; }          // pack 32/n windows, block-diagonal mask
+    }
+  } else {
+    // Q max-pooled inside each window (hieradet.py:64-67)
+    CHK(pool_tokens_f16_launch(ctx->ws_qk16, 2 * Co, ctx->ws_qp16, Co, M / (wcur * wcur), wcur, Co, s));
+    a.q = ctx->ws_qp16; a.ldq = Co;
+    const int nk = wcur * wcur, nq = nk / 4;
+    if (nq >= 32) { a.GQ = nq; a.GK = nk; a.wq = nq; a.wk = nk; a.num_groups = M / nk; }
+    else { const int pack = 32 / nq; a.GQ = 32; a.GK = pack * nk; a.wq = nq; a.wk = nk; a.num_groups = M / a.GK; }
+  }
+  CHKI(run_hiera_attn(ctx, s, a));
+  // 4. output projection + residual
+  {
+    GemmParams p = lin_params(ctx->ws_att16, Co, Mq, b.proj);
+    p.res = xres; p.ldres = Co; p.out32 = x; p.ld32 = Co;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  if (b.q_pool) { H /= 2; W /= 2; wcur /= 2; }
+  // 5-7. MLP
+  CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s));
+  {
+    GemmParams p = lin_params(ctx->ws_a16, Co, Mq, b.fc1);
+    p.act = ACT_GELU; p.out16 = ctx->ws_h16; p.ld16 = 4 * Co;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  {
+    GemmParams p = lin_params(ctx->ws_h16, 4 * Co, Mq, b.fc2);
+    p.res = x; p.ldres = Co; p.out32 = x; p.ld32 = Co;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  return 0;
+}
+
+// Runs patch embedding + all blocks; fills ctx->ws_lat[0..3] (neck laterals, window-major) and returns
+// the window size of each level's token order in wlev[].
+static int trunk_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, int wlev[4]) {
+  const sam2mi_config& c = ctx->cfg;
+  const int G = c.image_size / 4, E = c.embed_dim;
+  int H = G, W = G, wcur = 8;
+  // patch embed (conv 7x7 s4 p3 as im2col GEMM) + position table, written in window-major order
+  CHK(im2col_patch_launch(img, B, c.image_size, ctx->ws_a16, s));
+  {
+    GemmParams p = lin_params(ctx->ws_a16, 160, B * G * G, ctx->patch);
+    p.res = ctx->pos_tab; p.ldres = E; p.res_mod = G * G;
+    p.out32 = ctx->ws_x; p.ld32 = E;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  int level = 0;
+  for (size_t i = 0; i < ctx->blocks.size(); ++i) {
+    const HieraBlockW& b = ctx->blocks[i];
+    CHKI(hiera_block_forward(ctx, s, b, B, H, W, wcur));
+    // window size expected by the next block (hieradet.py:243-256: the window lags one block)
+    if (i + 1 < ctx->blocks.size()) {
+      const int wn = ctx->blocks[i + 1].window;
+      if (wn > 0 && wn != wcur) {
+        CHK(permute_tokens_launch(ctx->ws_x, ctx->ws_x2, B, H, W, b.dim_out, wcur, wn, nullptr, 0, s));
+        CHK(hipMemcpyAsync(ctx->ws_x, ctx->ws_x2, (size_t)B * H * W * b.dim_out * sizeof(float), hipMemcpyDeviceToDevice, s));
+        wcur = wn;
+      }
+    }
+    if (b.stage_end) {
+      // lateral 1x1 conv of the FPN on this stage's output (image_encoder.py:113-114)
+      const int M = B * H * W;
+      CHK(cast_add_launch(ctx->ws_x, b.dim_out, nullptr, 0, 0, 0.f, M, b.dim_out, ctx->ws_a16, b.dim_out, nullptr, 0, s));
+      GemmParams p = lin_params(ctx->ws_a16, b.dim_out, M, ctx->neck[level]);
+      p.out32 = ctx->ws_lat[level]; p.ld32 = 256;
+      CHKI(run_gemm(ctx, s, p));
+      wlev[level] = wcur;
+      ++level;
+    }
+  }
+  return level == 4 ? 0 : sam2mi_set_error(ctx, "trunk_forward", "expected 4 stage outputs");
+}
+
+int encoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, const EncOut* outs) {
+  const sam2mi_config& c = ctx->cfg;
+  if (!ctx->finalized) return sam2mi_set_error(ctx, "encoder_forward", "weights not finalized");
+  if (B <= 0 || B > c.max_batch) return sam2mi_set_error(ctx, "encoder_forward", "batch exceeds cfg.max_batch");
+  const int G = c.image_size / 4;
+  int wlev[4];
+  CHKI(trunk_forward(ctx, s, img, B, wlev));
+  // level 2 (64x64): lateral + nearest-2x of level 3, to row-major tokens  (fpn_top_down_levels [2,3], scalp 1)
+  {
+    float* dst = ctx->ws_x;   // staging [B, 4096, 256]
+    CHK(permute_tokens_launch(ctx->ws_lat[2], dst, B, G / 4, G / 4, 256, wlev[2], G / 4, ctx->ws_lat[3], wlev[3], s));
+    for (int b = 0; b < B; ++b)
+      CHK(hipMemcpyAsync(outs[b].feat2, dst + (size_t)b * 4096 * 256, (size_t)4096 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  // level 1 (128x128): conv_s1 (256 -> 64) on the lateral, then to row-major
+  {
+    const int M = B * (G / 2) * (G / 2);
+    CHK(cast_add_launch(ctx->ws_lat[1], 256, nullptr, 0, 0, 0.f, M, 256, ctx->ws_lat16, 256, nullptr, 0, s));
+    GemmParams p = lin_params(ctx->ws_lat16, 256, M, ctx->conv_s1);
+    p.out32 = ctx->ws_small; p.ld32 = 64;
+    CHKI(run_gemm(ctx, s, p));
+    float* dst = ctx->ws_x;
+    CHK(permute_tokens_launch(ctx->ws_small, dst, B, G / 2, G / 2, 64, wlev[1], G / 2, nullptr, 0, s));
+    for (int b = 0; b < B; ++b)
+      CHK(hipMemcpyAsync(outs[b].fpn1, dst + (size_t)b * 16384 * 64, (size_t)16384 * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  // level 0 (256x256): conv_s0 (256 -> 32)
+  {
+    const int M = B * G * G;
+    CHK(cast_add_launch(ctx->ws_lat[0], 256, nullptr, 0, 0, 0.f, M, 256, ctx->ws_lat16, 256, nullptr, 0, s));
+    GemmParams p = lin_params(ctx->ws_lat16, 256, M, ctx->conv_s0);
+    p.out32 = ctx->ws_small; p.ld32 = 32;
+    CHKI(run_gemm(ctx, s, p));
+    float* dst = ctx->ws_x;
+    CHK(permute_tokens_launch(ctx->ws_small, dst, B, G, G, 32, wlev[0], G, nullptr, 0, s));
+    for (int b = 0; b < B; ++b)
+      CHK(hipMemcpyAsync(outs[b].fpn0, dst + (size_t)b * 65536 * 32, (size_t)65536 * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  return 0;
+}

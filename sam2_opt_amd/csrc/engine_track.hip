@@ -1,0 +1,279 @@
+// Per-frame tracking stages: memory attention, two-way mask decoder + SAM heads, memory encoder.
+#include "engine.h"
+
+static const float LOG2E = 1.4426950408889634f;
+
+static inline int ceil32(int v) { return (v + 31) / 32 * 32; }
+
+static int pick_splits(int Nk) {
+  const int tiles = (Nk + 31) / 32;
+  int s = tiles / 16;
+  if (s < 1) s = 1;
+  if (s > 16) s = 16;
+  return s;
+}
+
+// MemoryAttention.inference_memory_attention_torch (modeling/memory_attention.py:299-349) with
+// MemoryAttentionLayer.forward (:93-109) and RoPEAttention.forward (sam/transformer.py:345-424).
+// Inputs: curr / curr_pos [4096,256] f32; ctx->t_kin16 / t_vin16 hold f16(memory+pos) / f16(memory)
+// for Nk keys of which the first n_rope get RoPE.  Output [4096,256] f32.
+int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const float* curr_pos, int Nk, int n_rope, float* out32) {
+  const int S = 4096, C = 256;
+  if (Nk <= 0 || ceil32(Nk) > ctx->t_nk_cap) return sam2mi_set_error(ctx, "memattn_forward", "memory length out of range");
+  const int NkP = ceil32(Nk);
+  float* x = ctx->t_x;
+  // x = curr + 0.1 * curr_pos   (pos_enc_at_input, :319-321)
+  CHK(cast_add_launch(curr, C, curr_pos, C, 0, 0.1f, S, C, nullptr, 0, x, C, s));
+  // K / V of the memory for all 4 layers at once: K_all [Nk, 4*256] (RoPE on rows < n_rope), V^T_all [4*256, NkP]
+  {
+    GemmParams p = lin_params(ctx->t_kin16, 64, Nk, ctx->cross_k_all);
+    p.out16 = ctx->t_kall16; p.ld16 = 1024;
+    p.rope_cos = ctx->rope_cos; p.rope_sin = ctx->rope_sin; p.rope_len = S; p.rope_rows = n_rope; p.rope_cols = 1024; p.rope_dim = C;
+    CHKI(run_gemm(ctx, s, p));
+    GemmParams q = lin_params(ctx->t_vin16, 64, Nk, ctx->cross_v_all);
+    q.n_split = 0; q.outT16 = ctx->t_vTall16; q.ldT16 = NkP;
+    CHKI(run_gemm(ctx, s, q));
+  }
+  for (int l = 0; l < 4; ++l) {
+    const MemAttnLayerW& L = ctx->mal[l];
+    // ---- self attention
+    CHK(layernorm_launch(x, C, L.n1.w, L.n1.b, 1e-5f, S, C, ctx->t_h16, C, nullptr, 0, 0, s));
+    {
+      GemmParams p = lin_params(ctx->t_h16, C, S, L.self_qkv);
+      p.n_split = 512; p.out16 = ctx->t_qk16; p.ld16 = 512; p.outT16 = ctx->t_vT16; p.ldT16 = S;
+      p.rope_cos = ctx->rope_cos; p.rope_sin = ctx->rope_sin; p.rope_len = S; p.rope_rows = S; p.rope_cols = 512; p.rope_dim = C;
+      CHKI(run_gemm(ctx, s, p));
+    }
+    {
+      Flash256Params f;
+      memset(&f, 0, sizeof(f));
+      f.q = ctx->t_qk16; f.ldq = 512; f.k = ctx->t_qk16 + 256; f.ldk = 512; f.vT = ctx->t_vT16; f.ldvT = S;
+      f.Nq = S; f.Nk = S; f.splits = pick_splits(S); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
+      f.out = ctx->t_o16; f.ldout = C; f.scale_log2e = LOG2E / 16.f;
+      CHKI(run_flash256(ctx, s, f));
+    }
+    {
+      GemmParams p = lin_params(ctx->t_o16, C, S, L.self_out);
+      p.res = x; p.ldres = C; p.out32 = x; p.ld32 = C;
+      CHKI(run_gemm(ctx, s, p));
+    }
+    // ---- cross attention to the memory bank
+    CHK(layernorm_launch(x, C, L.n2.w, L.n2.b, 1e-5f, S, C, ctx->t_h16, C, nullptr, 0, 0, s));
+    {
+      GemmParams p = lin_params(ctx->t_h16, C, S, L.cross_q);
+      p.out16 = ctx->t_q16; p.ld16 = C;
+      p.rope_cos = ctx->rope_cos; p.rope_sin = ctx->rope_sin; p.rope_len = S; p.rope_rows = S; p.rope_cols = C; p.rope_dim = C;
+      CHKI(run_gemm(ctx, s, p));
+    }
+    {
+      Flash256Params f;
+      memset(&f, 0, sizeof(f));
+      f.q = ctx->t_q16; f.ldq = C; f.k = ctx->t_kall16 + l * 256; f.ldk = 1024;
+      f.vT = ctx->t_vTall16 + (size_t)l * 256 * NkP; f.ldvT = NkP;
+      f.Nq = S; f.Nk = Nk; f.splits = pick_splits(Nk); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
+      f.out = ctx->t_o16; f.ldout = C; f.scale_log2e = LOG2E / 16.f;
+      CHKI(run_flash256(ctx, s, f));
+    }
+    {
+      GemmParams p = lin_params(ctx->t_o16, C, S, L.cross_out);
+      p.res = x; p.ldres = C; p.out32 = x; p.ld32 = C;
+      CHKI(run_gemm(ctx, s, p));
+    }
+    // ---- FFN
+    CHK(layernorm_launch(x, C, L.n3.w, L.n3.b, 1e-5f, S, C, ctx->t_h16, C, nullptr, 0, 0, s));
+    {
+      GemmParams p = lin_params(ctx->t_h16, C, S, L.lin1);
+      p.act = ACT_RELU; p.out16 = ctx->t_ff16; p.ld16 = 2048;
+      CHKI(run_gemm(ctx, s, p));
+      GemmParams q = lin_params(ctx->t_ff16, 2048, S, L.lin2);
+      q.res = x; q.ldres = C; q.out32 = x; q.ld32 = C;
+      CHKI(run_gemm(ctx, s, q));
+    }
+  }
+  CHK(layernorm_launch(x, C, ctx->ma_norm.w, ctx->ma_norm.b, 1e-5f, S, C, nullptr, 0, out32, C, 0, s));
+  return 0;
+}
+
+// ------------------------------------------------------------------ two-way transformer + output heads
+static int tok_linear(sam2mi_ctx* ctx, hipStream_t s, const float* x, int ldx, const Lin32& L, float* y, int ldy, int T, int act,
+                      const float* res = nullptr, int ldres = 0) {
+  CHK(small_linear_launch(x, ldx, L.w, L.b, y, ldy, res, ldres, T, L.N, L.K, act, s));
+  return 0;
+}
+static int tok_ln(sam2mi_ctx* ctx, hipStream_t s, float* x, const Norm& n, int T) {
+  CHK(layernorm_launch(x, 256, n.w, n.b, 1e-5f, T, 256, nullptr, 0, x, 256, 0, s));
+  return 0;
+}
+
+// token -> image attention: q tokens (+pe) against image keys (f16 operands in d_kpe16 / d_keys16)
+static int t2i_attention(sam2mi_ctx* ctx, hipStream_t s, const Lin32& Wq, const Lin16& Wk, const Lin16& Wv, const Lin32& Wo, int T) {
+  float* q = ctx->d_tok;            // [T,256]
+  // qq = q_proj(q + qpe)
+  CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, T, 256, nullptr, 0, ctx->d_tokpe, 256, s));
+  CHKI(tok_linear(ctx, s, ctx->d_tokpe, 256, Wq, ctx->d_t1, 128, T, 0));
+  GemmParams pk = lin_params(ctx->d_kpe16, 256, 4096, Wk);
+  pk.out32 = ctx->d_big1; pk.ld32 = 128;
+  CHKI(run_gemm(ctx, s, pk));
+  GemmParams pv = lin_params(ctx->d_keys16, 256, 4096, Wv);
+  pv.out32 = ctx->d_big2; pv.ld32 = 128;
+  CHKI(run_gemm(ctx, s, pv));
+  CHK(small_attn_launch(ctx->d_t1, 128, ctx->d_big1, 128, ctx->d_big2, 128, ctx->d_t2, 128, T, 4096, 8, 16, 1, 0, 0, 0, s));
+  // q = q + out_proj(att)
+  CHKI(tok_linear(ctx, s, ctx->d_t2, 128, Wo, q, 256, T, 0, q, 256));
+  return 0;
+}
+
+// refresh the f16 image-side operands from ctx->d_keys: keys16 = f16(keys), kpe16 = f16(keys + pos)
+static int refresh_key_operands(sam2mi_ctx* ctx, hipStream_t s, const float* pos_tok) {
+  CHK(cast_add_launch(ctx->d_keys, 256, nullptr, 0, 0, 0.f, 4096, 256, ctx->d_keys16, 256, nullptr, 0, s));
+  CHK(cast_add_launch(ctx->d_keys, 256, pos_tok, 256, 0, 1.f, 4096, 256, ctx->d_kpe16, 256, nullptr, 0, s));
+  return 0;
+}
+
+// MaskDecoder.inference_predict_masks_torch (modeling/sam/mask_decoder.py:262-316) + TwoWayTransformer
+// (sam/transformer.py:98-219) for one object.  keys_tok [4096,256] image embedding (token-major),
+// dense_tok [dense_rows,256] dense prompt embedding added to it (dense_rows = 1: broadcast no_mask_embed,
+// 4096: per-token; null: none), pos_tok [4096,256], tokens [T,256], hr0_tok [65536,32], hr1_tok [16384,64].
+// Results land in ctx->d_masks [4,65536], d_iou [4], d_mtok [4,256], d_obj [1].
+int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* keys_tok, const float* dense_tok, int dense_rows,
+                    const float* pos_tok, const float* tokens, int T, const float* hr0_tok, const float* hr1_tok) {
+  if (T < 6 || T > 64) return sam2mi_set_error(ctx, "decoder_forward", "token count out of range (6..64)");
+  // src = image_embeddings + dense_prompt_embeddings (mask_decoder.py:216)
+  CHK(cast_add_launch(keys_tok, 256, dense_tok, 256, dense_rows >= 4096 ? 0 : 1, 1.f, 4096, 256, nullptr, 0, ctx->d_keys, 256, s));
+  CHK(hipMemcpyAsync(ctx->d_tokens_in, tokens, (size_t)T * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));   // query_pe
+  CHK(hipMemcpyAsync(ctx->d_tok, tokens, (size_t)T * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  float* q = ctx->d_tok;
+  const char* stop_env = getenv("SAM2MI_DEC_STOP");
+  const int stop = stop_env ? atoi(stop_env) : -1;
+  int stage = 0;
+#define DBG_STAGE() do { if (stop >= 0 && stage++ == stop) return 0; } while (0)
+  for (int l = 0; l < 2; ++l) {
+    const DecLayerW& L = ctx->dec[l];
+    // ---- token self attention (layer 0: no pe, output replaces the queries; transformer.py:186-193)
+    const float* qin = q;
+    if (l > 0) {
+      CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, T, 256, nullptr, 0, ctx->d_tokpe, 256, s));
+      qin = ctx->d_tokpe;
+    }
+    CHKI(tok_linear(ctx, s, qin, 256, L.self_attn.q, ctx->d_t1, 256, T, 0));
+    CHKI(tok_linear(ctx, s, qin, 256, L.self_attn.k, ctx->d_t2, 256, T, 0));
+    CHKI(tok_linear(ctx, s, q, 256, L.self_attn.v, ctx->d_t3, 256, T, 0));
+    CHK(small_attn_launch(ctx->d_t1, 256, ctx->d_t2, 256, ctx->d_t3, 256, ctx->d_t4, 256, T, T, 8, 32, 1, 0, 0, 0, s));
+    CHKI(tok_linear(ctx, s, ctx->d_t4, 256, L.self_attn.o, q, 256, T, 0, l > 0 ? q : nullptr, 256));
+    CHKI(tok_ln(ctx, s, q, L.n1, T));
+    DBG_STAGE();   // 0 / 4
+    // ---- tokens attend to the image
+    CHKI(refresh_key_operands(ctx, s, pos_tok));
+    CHKI(t2i_attention(ctx, s, L.t2i_q, L.t2i_k, L.t2i_v, L.t2i_o, T));
+    CHKI(tok_ln(ctx, s, q, L.n2, T));
+    DBG_STAGE();   // 1 / 5
+    // ---- MLP on tokens
+    CHKI(tok_linear(ctx, s, q, 256, L.mlp1, ctx->d_t1, 2048, T, 2));
+    CHKI(tok_linear(ctx, s, ctx->d_t1, 2048, L.mlp2, q, 256, T, 0, q, 256));
+    CHKI(tok_ln(ctx, s, q, L.n3, T));
+    DBG_STAGE();   // 2 / 6
+    // ---- image attends to the tokens: q = (keys+pe) Wq, k = (tokens+pe) Wk, v = tokens Wv
+    {
+      GemmParams p = lin_params(ctx->d_kpe16, 256, 4096, L.i2t_q);
+      p.out32 = ctx->d_big1; p.ld32 = 128;
+      CHKI(run_gemm(ctx, s, p));
+      CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, T, 256, nullptr, 0, ctx->d_tokpe, 256, s));
+      CHKI(tok_linear(ctx, s, ctx->d_tokpe, 256, L.i2t_k, ctx->d_t1, 128, T, 0));
+      CHKI(tok_linear(ctx, s, q, 256, L.i2t_v, ctx->d_t2, 128, T, 0));
+      CHK(small_attn_launch(ctx->d_big1, 128, ctx->d_t1, 128, ctx->d_t2, 128, ctx->d_big2, 128, 4096, T, 8, 16, 1, 0, 0, 0, s));
+      CHK(cast_add_launch(ctx->d_big2, 128, nullptr, 0, 0, 0.f, 4096, 128, ctx->d_big16, 128, nullptr, 0, s));
+      GemmParams o = lin_params(ctx->d_big16, 128, 4096, L.i2t_o);
+      o.res = ctx->d_keys; o.ldres = 256; o.out32 = ctx->d_keys; o.ld32 = 256;
+      CHKI(run_gemm(ctx, s, o));
+      CHK(layernorm_launch(ctx->d_keys, 256, L.n4.w, L.n4.b, 1e-5f, 4096, 256, nullptr, 0, ctx->d_keys, 256, 0, s));
+    }
+    DBG_STAGE();   // 3 / 7
+  }
+  // ---- final token -> image attention + LN (transformer.py:134-139)
+  CHKI(refresh_key_operands(ctx, s, pos_tok));
+  CHKI(t2i_attention(ctx, s, ctx->fin_q, ctx->fin_k, ctx->fin_v, ctx->fin_o, T));
+  CHKI(tok_ln(ctx, s, q, ctx->fin_norm, T));
+  // hs = q: [0] obj score token, [1] iou token, [2..5] mask tokens
+  CHK(hipMemcpyAsync(ctx->d_mtok, q + 2 * 256, (size_t)4 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // ---- upscaling: ConvT(256->64) + hr1 -> LN2d -> GELU -> ConvT(64->32) + hr0 -> GELU  (mask_decoder.py:283-288)
+  {
+    GemmParams p = lin_params(ctx->d_keys16, 256, 4096, ctx->dc1);
+    p.out32 = ctx->d_g; p.ld32 = 256;
+    CHKI(run_gemm(ctx, s, p));
+    CHK(upscale_glue_launch(ctx->d_g, 64, 64, ctx->dc1_b, hr1_tok, ctx->up_ln.w, ctx->up_ln.b, ctx->d_up1_16, s));
+    GemmParams p2 = lin_params(ctx->d_up1_16, 64, 16384, ctx->dc2);
+    p2.out32 = ctx->d_g; p2.ld32 = 128;
+    CHKI(run_gemm(ctx, s, p2));
+    CHK(upscale_glue_launch(ctx->d_g, 128, 32, ctx->dc2_b, hr0_tok, nullptr, nullptr, ctx->d_up2_16, s));
+  }
+  // ---- hyper-network MLPs on the 4 mask tokens -> [4, 32]
+  for (int i = 0; i < 4; ++i) {
+    const float* tk = q + (size_t)(2 + i) * 256;
+    CHKI(tok_linear(ctx, s, tk, 256, ctx->hyper[i][0], ctx->d_t1, 256, 1, 2));
+    CHKI(tok_linear(ctx, s, ctx->d_t1, 256, ctx->hyper[i][1], ctx->d_t2, 256, 1, 2));
+    CHKI(tok_linear(ctx, s, ctx->d_t2, 256, ctx->hyper[i][2], ctx->d_hyper + i * 32, 32, 1, 0));
+  }
+  CHK(cast_add_launch(ctx->d_hyper, 32, nullptr, 0, 0, 0.f, 4, 32, ctx->d_hyper16, 32, nullptr, 0, s));
+  // masks[i, pix] = sum_c hyper[i, c] * up[pix, c]   (GEMM over pixels, stored transposed)
+  {
+    GemmParams p = gemm_params_zero();
+    p.A = ctx->d_up2_16; p.lda = 32; p.W = ctx->d_hyper16; p.ldw = 32; p.M = 65536; p.N = 4; p.K = 32;
+    p.n_split = 0; p.outT32 = ctx->d_masks; p.ldT32 = 65536;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  // ---- IoU head (sigmoid) and object-score head
+  CHKI(tok_linear(ctx, s, q + 256, 256, ctx->iou_head[0], ctx->d_t1, 256, 1, 2));
+  CHKI(tok_linear(ctx, s, ctx->d_t1, 256, ctx->iou_head[1], ctx->d_t2, 256, 1, 2));
+  CHKI(tok_linear(ctx, s, ctx->d_t2, 256, ctx->iou_head[2], ctx->d_iou, 4, 1, 3));
+  CHKI(tok_linear(ctx, s, q, 256, ctx->obj_head[0], ctx->d_t1, 256, 1, 2));
+  CHKI(tok_linear(ctx, s, ctx->d_t1, 256, ctx->obj_head[1], ctx->d_t2, 256, 1, 2));
+  CHKI(tok_linear(ctx, s, ctx->d_t2, 256, ctx->obj_head[2], ctx->d_obj, 1, 1, 0));
+  return 0;
+}
+
+// ------------------------------------------------------------------ memory encoder
+// MemoryEncoder.inference_memory_torch (modeling/memory_encoder.py:233-241): feat2_tok [4096,256] raw
+// vision features, mask1024 [1024*1024] already sigmoid-scaled -> out_tok64 [4096,64] f32.
+int memenc_forward(sam2mi_ctx* ctx, hipStream_t s, const float* feat2_tok, const float* mask1024, float* out_tok64) {
+  // MaskDownSampler: 4 x (conv3x3 s2 + LN2d + GELU), then 1x1
+  CHK(conv3x3s2_ln_gelu_launch(mask1024, 1024, 1, 4, ctx->md_w[0], ctx->md_b[0], ctx->md_ln[0].w, ctx->md_ln[0].b, ctx->m_c1, nullptr, s));
+  CHK(conv3x3s2_ln_gelu_launch(ctx->m_c1, 512, 4, 16, ctx->md_w[1], ctx->md_b[1], ctx->md_ln[1].w, ctx->md_ln[1].b, ctx->m_c2, nullptr, s));
+  CHK(conv3x3s2_ln_gelu_launch(ctx->m_c2, 256, 16, 64, ctx->md_w[2], ctx->md_b[2], ctx->md_ln[2].w, ctx->md_ln[2].b, nullptr, ctx->m_c3_16, s));
+  CHK(im2col3x3s2_launch(ctx->m_c3_16, 128, 64, ctx->m_col16, s));
+  {
+    GemmParams p = lin_params(ctx->m_col16, 576, 4096, ctx->md_conv4);
+    p.out32 = ctx->m_c4; p.ld32 = 256;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  CHK(layernorm_launch(ctx->m_c4, 256, ctx->md_ln[3].w, ctx->md_ln[3].b, 1e-6f, 4096, 256, ctx->m_c4_16, 256, nullptr, 0, 1, s));
+  {
+    GemmParams p = lin_params(ctx->m_c4_16, 256, 4096, ctx->md_proj);
+    p.out32 = ctx->m_emb; p.ld32 = 256;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  // x = pix_feat_proj(pix_feat) + mask embedding
+  CHK(cast_add_launch(feat2_tok, 256, nullptr, 0, 0, 0.f, 4096, 256, ctx->m_pix16, 256, nullptr, 0, s));
+  {
+    GemmParams p = lin_params(ctx->m_pix16, 256, 4096, ctx->pix_proj);
+    p.res = ctx->m_emb; p.ldres = 256; p.out32 = ctx->m_x; p.ld32 = 256;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  // Fuser: 2 x CXBlock (dwconv7 -> LN2d -> 256->1024 GELU -> 1024->256 -> gamma -> + x)
+  for (int l = 0; l < 2; ++l) {
+    CHK(dwconv7_launch(ctx->m_x, 64, 256, ctx->cx[l].dw_w, ctx->cx[l].dw_b, ctx->m_dw, s));
+    CHK(layernorm_launch(ctx->m_dw, 256, ctx->cx[l].ln.w, ctx->cx[l].ln.b, 1e-6f, 4096, 256, ctx->m_ln16, 256, nullptr, 0, 0, s));
+    GemmParams p = lin_params(ctx->m_ln16, 256, 4096, ctx->cx[l].pw1);
+    p.act = ACT_GELU; p.out16 = ctx->m_h16; p.ld16 = 1024;
+    CHKI(run_gemm(ctx, s, p));
+    GemmParams q = lin_params(ctx->m_h16, 1024, 4096, ctx->cx[l].pw2);
+    q.col_scale = ctx->cx[l].gamma; q.res = ctx->m_x; q.ldres = 256; q.out32 = ctx->m_x; q.ld32 = 256;
+    CHKI(run_gemm(ctx, s, q));
+  }
+  CHK(cast_add_launch(ctx->m_x, 256, nullptr, 0, 0, 0.f, 4096, 256, ctx->m_ln16, 256, nullptr, 0, s));
+  {
+    GemmParams p = lin_params(ctx->m_ln16, 256, 4096, ctx->me_out);
+    p.out32 = out_tok64; p.ld32 = 64;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  return 0;
+}

@@ -212,7 +212,7 @@ static hipError_t gemm_dispatch_tile(const GemmParams& p, hipStream_t s) {
 
 hipError_t gemm_launch(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
-  if ((p.lda & 7) || (p.ldw & 7) || (p.n_split & 31) || p.K <= 0) return hipErrorInvalidValue;
+  if ((p.lda & 7) || (p.ldw & 7) || (p.n_split < p.N && (p.n_split & 31)) || p.K <= 0) return hipErrorInvalidValue;
   if (p.K % 64 == 0) return gemm_dispatch_tile<64>(p, s);
   if (p.K % 48 == 0) return gemm_dispatch_tile<48>(p, s);
   if (p.K % 32 == 0) return gemm_dispatch_tile<32>(p, s);

@@ -1,0 +1,248 @@
+// Prompt encoder, mask-decoder glue and memory-bank assembly kernels.  Everything here is tiny and
+// latency-bound: fp32 SIMT, one wave per output row/column, no host synchronisation (decisions such
+// as the IoU argmax or the object-score gate stay on the device).
+#include "kernels.h"
+
+namespace {
+constexpr float NO_OBJ_SCORE = -1024.f;     // modeling/sam2_base_official.py:21
+constexpr float TWO_PI = 6.283185307179586f;
+
+// y[t, n] for all t: one wave per n
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
+                                                           const float* __restrict__ b, float* y, int ldy, const float* res,
+                                                           int ldres, int T, int N, int K, int act) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const float* wr = W + (size_t)n * K;
+  for (int t0 = 0; t0 < T; t0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float wv = wr[k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (t0 + j < T) acc[j] += wv * x[(size_t)(t0 + j) * ldx + k];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = wave_sum(acc[j]);
+      if (lane == 0 && t0 + j < T) {
+        float o = v + (b ? b[n] : 0.f);
+        if (act == 2) o = fmaxf(o, 0.f);
+        else if (act == 3) o = 1.f / (1.f + expf(-o));
+        if (res) o += res[(size_t)(t0 + j) * ldres + n];
+        y[(size_t)(t0 + j) * ldy + n] = o;
+      }
+    }
+  }
+}
+
+// PromptEncoder._embed_points (+ pad point), prompt_encoder.py:124-166 / position_encoding.py:148-175
+__global__ void point_embed_kernel(const float* __restrict__ pts, const int* __restrict__ labels, int Np,
+                                   const float* __restrict__ gauss, const float* __restrict__ pe4,
+                                   const float* __restrict__ nap, float image_size, float* __restrict__ out) {
+  const int i = blockIdx.x;             // point index (Np = pad point)
+  const int c = threadIdx.x;            // 0..255
+  float px = 0.f, py = 0.f;
+  int lab = -1;
+  if (i < Np) {
+    px = pts[2 * i] + 0.5f;
+    py = pts[2 * i + 1] + 0.5f;
+    lab = labels[i];
+  }
+  const float cx = 2.f * (px / image_size) - 1.f, cy = 2.f * (py / image_size) - 1.f;
+  const int f = c & 127;
+  const float ang = TWO_PI * (cx * gauss[f] + cy * gauss[128 + f]);
+  float v = (c < 128) ? sinf(ang) : cosf(ang);
+  if (lab == -1) v = nap[c];
+  else if (lab >= 0 && lab < 4) v += pe4[lab * 256 + c];
+  out[(size_t)i * 256 + c] = v;
+}
+
+// PromptEncoder.get_dense_pe: token (y, x) -> coords ((x+0.5)/S, (y+0.5)/S)
+__global__ void dense_pe_kernel(const float* __restrict__ gauss, int S, float* __restrict__ out) {
+  const int t = blockIdx.x, c = threadIdx.x;
+  const int y = t / S, x = t % S;
+  const float cx = 2.f * ((x + 0.5f) / S) - 1.f, cy = 2.f * ((y + 0.5f) / S) - 1.f;
+  const int f = c & 127;
+  const float ang = TWO_PI * (cx * gauss[f] + cy * gauss[128 + f]);
+  out[(size_t)t * 256 + c] = (c < 128) ? sinf(ang) : cosf(ang);
+}
+
+// one wave per output pixel (2Hin x 2Hin grid), C <= 64 channels (lane = channel)
+__global__ __launch_bounds__(256) void upscale_glue_kernel(const float* __restrict__ g, int Hin, int C, const float* __restrict__ bias,
+                                                           const float* __restrict__ hr, const float* __restrict__ lnw,
+                                                           const float* __restrict__ lnb, half_t* __restrict__ out16) {
+  const int Hout = 2 * Hin;
+  const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (pix >= Hout * Hout) return;
+  const int Y = pix / Hout, X = pix % Hout;
+  const int src = (Y >> 1) * Hin + (X >> 1), pos = (Y & 1) * 2 + (X & 1);
+  const bool on = lane < C;
+  float v = on ? g[(size_t)src * 4 * C + pos * C + lane] + bias[lane] + hr[(size_t)pix * C + lane] : 0.f;
+  if (lnw) {
+    const float mean = wave_sum(v) / C;
+    const float d = on ? v - mean : 0.f;
+    const float rstd = 1.f / sqrtf(wave_sum(d * d) / C + 1e-6f);
+    v = on ? d * rstd * lnw[lane] + lnb[lane] : 0.f;
+  }
+  if (on) out16[(size_t)pix * C + lane] = (half_t)gelu_erf(v);
+}
+
+// stability score inputs of MaskDecoder._get_stability_scores (mask_decoder.py:332-344) for mask 0
+__global__ void stability_count_kernel(const float* __restrict__ mask0, float delta, int* counts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float v = i < 65536 ? mask0[i] : -1e30f;
+  const unsigned long long bi = __ballot(v > delta), bu = __ballot(v > -delta);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&counts[0], __popcll(bi));
+    atomicAdd(&counts[1], __popcll(bu));
+  }
+}
+
+// SAM2Base._forward_sam_heads :440-484 + MaskDecoder.forward :151-169.
+//  multimask: candidates 1..3, best by IoU, its token.  Otherwise candidate 0 unless its stability score
+//  (counts from stability_count_kernel) is below `stab_thresh`, then the best of 1..3 (token stays token 0).
+__global__ void select_mask_kernel(const float* __restrict__ masks, const float* __restrict__ iou, const float* __restrict__ obj,
+                                   const float* __restrict__ tokens, int multimask, const int* __restrict__ counts,
+                                   float stab_thresh, float* low_multi, float* low_sel, float* tok_sel, int* best_idx,
+                                   float* iou_out) {
+  const bool appearing = obj[0] > 0.f;
+  int bm = 1;
+  float bv = iou[1];
+  if (iou[2] > bv) { bv = iou[2]; bm = 2; }
+  if (iou[3] > bv) { bv = iou[3]; bm = 3; }
+  int best, tok_idx;
+  if (multimask) {
+    best = bm;
+    tok_idx = bm;
+  } else {
+    float stab = 1.f;
+    if (counts && counts[1] > 0) stab = (float)counts[0] / (float)counts[1];
+    best = (!counts || stab >= stab_thresh) ? 0 : bm;
+    tok_idx = 0;
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 65536) {
+    low_sel[i] = appearing ? masks[(size_t)best * 65536 + i] : NO_OBJ_SCORE;
+    if (low_multi) {
+      if (multimask) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) low_multi[(size_t)k * 65536 + i] = appearing ? masks[(size_t)(k + 1) * 65536 + i] : NO_OBJ_SCORE;
+      } else {
+        low_multi[i] = appearing ? masks[(size_t)best * 65536 + i] : NO_OBJ_SCORE;
+      }
+    }
+  }
+  if (i < 256) tok_sel[i] = tokens[tok_idx * 256 + i];
+  if (i == 0) {
+    best_idx[0] = multimask ? best - 1 : best;
+    if (iou_out) {
+      if (multimask) { iou_out[0] = iou[1]; iou_out[1] = iou[2]; iou_out[2] = iou[3]; }
+      else iou_out[0] = iou[best];
+    }
+  }
+}
+
+__global__ void gate_obj_ptr_kernel(float* ptr, const float* __restrict__ no_obj_ptr, const float* __restrict__ obj, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float lam = obj[0] > 0.f ? 1.f : 0.f;
+  ptr[c] = lam * ptr[c] + (1.f - lam) * no_obj_ptr[c];
+}
+
+__global__ void mem_assemble_kernel(const MemAssembleParams p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nframe = (size_t)p.L * 4096 * 64;
+  const size_t total = nframe + (size_t)p.P * 64;
+  if (i >= total) return;
+  float f, ps;
+  if (i < nframe) {
+    const int s = (int)(i / (4096 * 64));
+    const int r = (int)(i % (4096 * 64));
+    f = p.feat[s][r];
+    ps = p.pos[r] + p.tpos[s][r & 63];
+  } else {
+    const size_t r = i - nframe;
+    f = p.ptr_tok[r];
+    ps = p.ptr_pos[r];
+  }
+  p.kin[i] = (half_t)(f + ps);
+  p.vin[i] = (half_t)f;
+  if (p.mem32) p.mem32[i] = f;
+  if (p.mempos32) p.mempos32[i] = ps;
+}
+
+// one block (64 threads = 64 output features) per pointer
+__global__ void ptr_tokens_kernel(const PtrTokParams p) {
+  __shared__ float pe[256];
+  const int i = blockIdx.x, t = threadIdx.x;
+  const float pos = p.dt[i] / p.tmax;
+  for (int j = t; j < 128; j += 64) {
+    const float dim_t = powf(10000.f, 2.f * (float)(j / 2) / 128.f);
+    const float e = pos / dim_t;
+    pe[j] = sinf(e);
+    pe[128 + j] = cosf(e);
+  }
+  __syncthreads();
+  float acc = p.bt[t];
+  const float* wr = p.Wt + (size_t)t * 256;
+  for (int k = 0; k < 256; ++k) acc += wr[k] * pe[k];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    p.pos[((size_t)4 * i + j) * 64 + t] = acc;
+    p.tok[((size_t)4 * i + j) * 64 + t] = p.ptr[i][64 * j + t];
+  }
+}
+}  // namespace
+
+hipError_t small_linear_launch(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, const float* res,
+                               int ldres, int T, int N, int K, int act, hipStream_t s) {
+  small_linear_kernel<<<dim3((N + 3) / 4), dim3(256), 0, s>>>(x, ldx, W, b, y, ldy, res, ldres, T, N, K, act);
+  return hipGetLastError();
+}
+hipError_t point_embed_launch(const float* pts, const int* labels, int Np, const float* gauss, const float* point_emb4,
+                              const float* not_a_point, float image_size, float* out, hipStream_t s) {
+  point_embed_kernel<<<dim3(Np + 1), dim3(256), 0, s>>>(pts, labels, Np, gauss, point_emb4, not_a_point, image_size, out);
+  return hipGetLastError();
+}
+hipError_t dense_pe_launch(const float* gauss, int S, float* out, hipStream_t s) {
+  dense_pe_kernel<<<dim3(S * S), dim3(256), 0, s>>>(gauss, S, out);
+  return hipGetLastError();
+}
+hipError_t upscale_glue_launch(const float* g, int Hin, int C, const float* bias, const float* hr, const float* lnw,
+                               const float* lnb, half_t* out16, hipStream_t s) {
+  if (C > 64) return hipErrorInvalidValue;
+  const int n = 4 * Hin * Hin;
+  upscale_glue_kernel<<<dim3((n + 3) / 4), dim3(256), 0, s>>>(g, Hin, C, bias, hr, lnw, lnb, out16);
+  return hipGetLastError();
+}
+hipError_t select_mask_launch(const float* masks, const float* iou, const float* obj, const float* tokens, int multimask,
+                              int* stab_counts, float stab_delta, float stab_thresh, float* low_multi, float* low_sel,
+                              float* tok_sel, int* best_idx, float* iou_out, hipStream_t s) {
+  if (!multimask && stab_counts) {
+    hipError_t e = hipMemsetAsync(stab_counts, 0, 2 * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    stability_count_kernel<<<dim3(256), dim3(256), 0, s>>>(masks, stab_delta, stab_counts);
+  }
+  select_mask_kernel<<<dim3(256), dim3(256), 0, s>>>(masks, iou, obj, tokens, multimask, multimask ? nullptr : stab_counts,
+                                                     stab_thresh, low_multi, low_sel, tok_sel, best_idx, iou_out);
+  return hipGetLastError();
+}
+hipError_t gate_obj_ptr_launch(float* ptr, const float* no_obj_ptr, const float* obj, int C, hipStream_t s) {
+  gate_obj_ptr_kernel<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(ptr, no_obj_ptr, obj, C);
+  return hipGetLastError();
+}
+hipError_t mem_assemble_launch(const MemAssembleParams& p, hipStream_t s) {
+  const size_t total = (size_t)p.L * 4096 * 64 + (size_t)p.P * 64;
+  mem_assemble_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(p);
+  return hipGetLastError();
+}
+hipError_t ptr_tokens_launch(const PtrTokParams& p, hipStream_t s) {
+  if (p.n <= 0) return hipSuccess;
+  ptr_tokens_kernel<<<dim3(p.n), dim3(64), 0, s>>>(p);
+  return hipGetLastError();
+}

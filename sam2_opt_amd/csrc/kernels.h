@@ -1,0 +1,83 @@
+// Launchers for the non-GEMM, non-attention kernels (elementwise.hip, convs.hip, heads.hip).
+// All take raw device pointers; token-major ("tok") tensors are [rows, channels] row-major.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------- elementwise.hip
+// LayerNorm over the last dim of x [M, C] (ldx) -> y16 (f16, ldy16) and/or y32 (f32, ldy32); act: 0 none, 1 GELU
+hipError_t layernorm_launch(const float* x, int ldx, const float* w, const float* b, float eps, int M, int C,
+                            half_t* y16, int ldy16, float* y32, int ldy32, int act, hipStream_t s);
+// y16[m, c] = f16(a[m, c] + sb * b[(m % bmod), c]);  b may be null; bmod == 0 -> m.  Optional y32 copy.
+hipError_t cast_add_launch(const float* a, int lda, const float* b, int ldb, int bmod, float sb, int M, int C,
+                           half_t* y16, int ldy16, float* y32, int ldy32, hipStream_t s);
+// patch-embed im2col: img [B,3,S,S] f32 -> A [B*(S/4)^2, 160] f16, rows in window-major (w=8) token order,
+// column k = c*49 + ky*7 + kx (conv 7x7, stride 4, pad 3); columns 147..159 are zero.
+hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStream_t s);
+// 2x2 max-pool inside w x w windows of window-major tokens: in [nwin*w*w, C] -> out [nwin*(w/2)^2, C]
+hipError_t pool_tokens_f32_launch(const float* in, int ldin, float* out, int ldout, int nwin, int w, int C, hipStream_t s);
+hipError_t pool_tokens_f16_launch(const half_t* in, int ldin, half_t* out, int ldout, int nwin, int w, int C, hipStream_t s);
+// reorder tokens of B grids (H x W) from window size w_in to window size w_out (w == W means row-major);
+// optional add of a nearest-2x-upsampled coarser grid `up` (H/2 x W/2, window size w_up).
+hipError_t permute_tokens_launch(const float* in, float* out, int B, int H, int W, int C, int w_in, int w_out,
+                                 const float* up, int w_up, hipStream_t s);
+// batched 2-D transpose f32: in [batch, R, Cc] -> out [batch, Cc, R]
+hipError_t transpose_f32_launch(const float* in, float* out, int batch, int R, int Cc, hipStream_t s);
+// out[m, c] += v[c] * (flag_ptr ? (1 - (flag[0] > 0)) : 1)
+hipError_t add_rowvec_launch(float* x, int ld, const float* v, int M, int C, const float* flag, hipStream_t s);
+// round-to-nearest-even to bf16 precision, kept as f32 (the reference stores the memory bank as bf16)
+hipError_t round_bf16_launch(const float* in, float* out, size_t n, hipStream_t s);
+// fill f16 / f32
+hipError_t fill_f32_launch(float* p, float v, size_t n, hipStream_t s);
+
+// ---------------------------------------------------------------- convs.hip (memory encoder)
+// bilinear x4 upsample (align_corners=False) of low [256*256] + (binarize ? (x>0) : sigmoid(x)) * scale + bias -> out [1024*1024]
+hipError_t mask_prep_launch(const float* low, float* out, int binarize, float scale, float bias, hipStream_t s);
+// direct conv 3x3 stride 2 pad 1 on NHWC f32 + bias + LayerNorm2d(eps 1e-6) + GELU; in [Hin*Hin, CIN] -> out [Hout*Hout, COUT]
+hipError_t conv3x3s2_ln_gelu_launch(const float* in, int Hin, int CIN, int COUT, const float* w, const float* b,
+                                    const float* lnw, const float* lnb, float* out32, half_t* out16, hipStream_t s);
+// im2col for a 3x3 s2 p1 conv on NHWC f16: in [Hin*Hin, CIN] -> A [Hout*Hout, 9*CIN], column (ky*3+kx)*CIN + c
+hipError_t im2col3x3s2_launch(const half_t* in, int Hin, int CIN, half_t* A, hipStream_t s);
+// depth-wise 7x7 pad 3 on NHWC f32 [H*H, C]; w [C, 49]
+hipError_t dwconv7_launch(const float* in, int H, int C, const float* w, const float* b, float* out, hipStream_t s);
+
+// ---------------------------------------------------------------- heads.hip (prompt encoder, mask decoder glue)
+// y[t, n] = act(sum_k x[t, k] W[n, k] + b[n]) (+ res[t, n]);  f32 everywhere, T <= 64.  act: 0 none, 2 relu, 3 sigmoid
+hipError_t small_linear_launch(const float* x, int ldx, const float* W, const float* b, float* y, int ldy,
+                               const float* res, int ldres, int T, int N, int K, int act, hipStream_t s);
+// sparse point embeddings (PromptEncoder._embed_points): pts [Np,2] px, labels [Np] -> out [Np+1, 256] (pad point appended)
+hipError_t point_embed_launch(const float* pts, const int* labels, int Np, const float* gauss, const float* point_emb4,
+                              const float* not_a_point, float image_size, float* out, hipStream_t s);
+// dense positional encoding grid (PromptEncoder.get_dense_pe) -> out [64*64, 256] token-major
+hipError_t dense_pe_launch(const float* gauss, int S, float* out, hipStream_t s);
+// ConvTranspose 2x2 s2 glue.  g [Hin*Hin, 4*C] (GEMM output, column pos*C + c, pos = dy*2+dx) + bias[c] + hr [ (2Hin)^2, C ]
+// -> (LayerNorm2d if lnw) -> GELU -> out16 [(2Hin)^2, C]
+hipError_t upscale_glue_launch(const float* g, int Hin, int C, const float* bias, const float* hr, const float* lnw,
+                               const float* lnb, half_t* out16, hipStream_t s);
+// SAM-head selection on device (SAM2Base._forward_sam_heads :440-484, MaskDecoder.forward :151-169):
+//  masks [4, 65536], iou [4], obj [1], tokens [4,256]  ->  low_sel [65536] (NO_OBJ filled when obj<=0),
+//  tok_sel [256], best_idx [1].  multimask: argmax-IoU over candidates 1..3; otherwise candidate 0 with the
+//  dynamic stability fallback (stab_counts: 2-int scratch; null disables the fallback).
+hipError_t select_mask_launch(const float* masks, const float* iou, const float* obj, const float* tokens, int multimask,
+                              int* stab_counts, float stab_delta, float stab_thresh, float* low_multi, float* low_sel,
+                              float* tok_sel, int* best_idx, float* iou_out, hipStream_t s);
+// obj_ptr = lam * ptr + (1 - lam) * no_obj_ptr, lam = obj > 0
+hipError_t gate_obj_ptr_launch(float* ptr, const float* no_obj_ptr, const float* obj, int C, hipStream_t s);
+// memory-bank K/V operand assembly: for slot s (0..L-1) rows [s*4096, (s+1)*4096):
+//   kin = f16(feat_s + pos + tpos_s), vin = f16(feat_s); pointer tokens appended after the L frames.
+struct MemAssembleParams {
+  const float* feat[8]; const float* tpos[8]; int L;        // feat_s [4096,64] f32 (bf16-rounded), tpos_s [64]
+  const float* pos;                                          // maskmem_pos_enc [4096,64]
+  const float* ptr_tok; const float* ptr_pos; int P;         // [P,64] each (already split into 64-wide tokens)
+  half_t* kin; half_t* vin;                                  // [L*4096 + P (padded), 64]
+  float* mem32; float* mempos32;                             // optional f32 copies (plug-format debugging)
+};
+hipError_t mem_assemble_launch(const MemAssembleParams& p, hipStream_t s);
+// object-pointer tokens: ptr[i] [256] f32 -> tok rows [4*i + j] = ptr[i][64*j .. 64*j+64);
+// pos rows 4*i+j = Linear_{256->64}( [sin(dt_i/tmax / dim_t), cos(...)] )   (get_1d_sine_pe, sam2_utils.py:64-74)
+struct PtrTokParams {
+  const float* ptr[32]; float dt[32]; int n;
+  float tmax;
+  const float* Wt; const float* bt;     // obj_ptr_tpos_proj (64, 256) f32
+  float* tok; float* pos;               // [4n, 64] each
+};
+hipError_t ptr_tokens_launch(const PtrTokParams& p, hipStream_t s);

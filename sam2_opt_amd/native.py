@@ -1,0 +1,282 @@
+"""ctypes binding of libsam2mi.so (include/sam2mi.h).  There is NO fallback: if the HIP library is
+missing or no MI355X is visible, construction raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from .config import get_config
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsam2mi.so")
+
+EXPORTS = [
+    "sam2mi_abi_version", "sam2mi_create", "sam2mi_destroy", "sam2mi_last_error", "sam2mi_load_weight",
+    "sam2mi_finalize_weights", "sam2mi_image_encoder", "sam2mi_set_image_e2e", "sam2mi_memory_attention",
+    "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_dense_pe", "sam2mi_video_encode",
+    "sam2mi_video_click", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_resize_bilinear",
+    "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
+    "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read",
+]
+
+
+class Sam2miConfig(C.Structure):
+    _fields_ = [("embed_dim", C.c_int), ("num_heads", C.c_int), ("stages", C.c_int * 4),
+                ("global_att_blocks", C.c_int * 8), ("window_spec", C.c_int * 4), ("image_size", C.c_int),
+                ("max_batch", C.c_int), ("bank_slots", C.c_int), ("feat_slots", C.c_int)]
+
+
+class MemSelect(C.Structure):
+    _fields_ = [("num_mem", C.c_int), ("mem_slot", C.c_int * 16), ("mem_tpos", C.c_int * 16), ("num_ptr", C.c_int),
+                ("ptr_slot", C.c_int * 32), ("ptr_dt", C.c_float * 32), ("ptr_tmax", C.c_float)]
+
+
+class FrameOut(C.Structure):
+    _fields_ = [("low_res_masks", C.c_void_p), ("low_res_multimasks", C.c_void_p), ("ious", C.c_void_p),
+                ("obj_ptr", C.c_void_p), ("object_score_logits", C.c_void_p), ("pix_feat", C.c_void_p),
+                ("best_idx", C.c_void_p)]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libsam2mi.so; raises with build instructions when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `python -m sam2_opt_amd.build` "
+                               "(hipcc --offload-arch=gfx950). This backend has no CPU/PyTorch fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            if not hasattr(lib, name):
+                raise RuntimeError(f"libsam2mi.so does not export {name}")
+        lib.sam2mi_last_error.restype = C.c_char_p
+        lib.sam2mi_last_error.argtypes = [C.c_void_p]
+        lib.sam2mi_create.argtypes = [C.POINTER(Sam2miConfig), C.POINTER(C.c_void_p)]
+        lib.sam2mi_destroy.argtypes = [C.c_void_p]
+        lib.sam2mi_destroy.restype = None
+        _lib = lib
+    return _lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+
+
+class Engine:
+    """One sam2mi context (one per host thread / stream)."""
+
+    def __init__(self, model: str = "large", state_dict=None, max_batch: int = 1, bank_slots: int = 64,
+                 feat_slots: int = 16, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("sam2_opt_amd needs a ROCm GPU (MI355X); no CPU fallback exists")
+        self.lib = load_library()
+        self.cfg = get_config(model) if isinstance(model, str) else model
+        dev = torch.device(device if device is not None else "cuda")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        torch.cuda.set_device(self.device)
+        c = Sam2miConfig()
+        c.embed_dim, c.num_heads, c.image_size = self.cfg["embed_dim"], self.cfg["num_heads"], self.cfg["image_size"]
+        for i in range(4):
+            c.stages[i] = self.cfg["stages"][i]
+            c.window_spec[i] = self.cfg["window_spec"][i]
+        for i in range(8):
+            c.global_att_blocks[i] = self.cfg["global_att_blocks"][i] if i < len(self.cfg["global_att_blocks"]) else -1
+        c.max_batch, c.bank_slots, c.feat_slots = max_batch, bank_slots, max(feat_slots, max_batch)
+        self.max_batch, self.bank_slots, self.feat_slots = max_batch, bank_slots, c.feat_slots
+        h = C.c_void_p()
+        if self.lib.sam2mi_create(C.byref(c), C.byref(h)) != 0:
+            raise RuntimeError("sam2mi_create failed: " + self.lib.sam2mi_last_error(None).decode())
+        self.h = h
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    # ------------------------------------------------------------------ infrastructure
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: {self.lib.sam2mi_last_error(self.h).decode()}")
+
+    @property
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.sam2mi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, sd):
+        """Strict load of a SAM 2.1 `state_dict` (checkpoint["model"]); cf. build_sam._load_checkpoint."""
+        for k, v in sd.items():
+            a = v.detach().to(torch.float32).cpu().contiguous().numpy() if isinstance(v, torch.Tensor) else np.ascontiguousarray(v, np.float32)
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            rc = self.lib.sam2mi_load_weight(self.h, k.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), shape, a.ndim)
+            self._check(rc, f"sam2mi_load_weight({k})")
+        self._check(self.lib.sam2mi_finalize_weights(self.h), "sam2mi_finalize_weights")
+
+    def new(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    # ------------------------------------------------------------------ plug-level API (reference layouts)
+    def image_encoder(self, img: torch.Tensor):
+        """SAM2Base.inference_image: (B,3,1024,1024) -> 7-tuple."""
+        _chk_f32(img)
+        B = img.shape[0]
+        outs = [self.new(B, 256, 64, 64), self.new(B, 256, 256, 256), self.new(B, 256, 128, 128), self.new(B, 256, 64, 64),
+                self.new(B, 32, 256, 256), self.new(B, 64, 128, 128), self.new(B, 256, 64, 64)]
+        arr = (C.c_void_p * 7)(*[o.data_ptr() for o in outs])
+        self._check(self.lib.sam2mi_image_encoder(self.h, self.stream, _ptr(img), B, arr), "sam2mi_image_encoder")
+        return tuple(outs)
+
+    def set_image_e2e(self, img01: torch.Tensor):
+        _chk_f32(img01)
+        B = img01.shape[0]
+        f0, f1, f2 = self.new(B, 32, 256, 256), self.new(B, 64, 128, 128), self.new(B, 256, 64, 64)
+        self._check(self.lib.sam2mi_set_image_e2e(self.h, self.stream, _ptr(img01), B, _ptr(f0), _ptr(f1), _ptr(f2)),
+                    "sam2mi_set_image_e2e")
+        return f0, f1, f2
+
+    def memory_attention(self, curr, memory, curr_pos, memory_pos, memory_exclude, memory_pos_exclude):
+        L, P, N = memory.shape[0], memory_exclude.shape[0], curr.shape[1]
+        ts = [t.contiguous() for t in (curr, memory, curr_pos, memory_pos, memory_exclude, memory_pos_exclude)]
+        _chk_f32(*ts)
+        out = self.new(*curr.shape)
+        self._check(self.lib.sam2mi_memory_attention(self.h, self.stream, *[_ptr(t) for t in ts], L, P, N, _ptr(out)),
+                    "sam2mi_memory_attention")
+        return out
+
+    def mask_decoder(self, src, tokens, pos_src, hr0, hr1):
+        ts = [t.contiguous() for t in (src, tokens, pos_src, hr0, hr1)]
+        _chk_f32(*ts)
+        N, T = tokens.shape[0], tokens.shape[1]
+        masks, iou, tok, obj = self.new(N, 4, 256, 256), self.new(N, 4), self.new(N, 4, 256), self.new(N, 1)
+        self._check(self.lib.sam2mi_mask_decoder(self.h, self.stream, *[_ptr(t) for t in ts], N, T, _ptr(masks), _ptr(iou),
+                                                 _ptr(tok), _ptr(obj)), "sam2mi_mask_decoder")
+        return masks, iou, tok, obj
+
+    def memory_encoder(self, pix_feat, masks):
+        pix_feat, masks = pix_feat.contiguous(), masks.contiguous()
+        _chk_f32(pix_feat, masks)
+        N = pix_feat.shape[0]
+        x, pos = self.new(N, 64, 64, 64), self.new(N, 64, 64, 64)
+        self._check(self.lib.sam2mi_memory_encoder(self.h, self.stream, _ptr(pix_feat), _ptr(masks), N, _ptr(x), _ptr(pos)),
+                    "sam2mi_memory_encoder")
+        return x, pos
+
+    def prompt_encoder(self, coords, labels):
+        coords = coords.contiguous().to(torch.float32)
+        labels = labels.contiguous().to(torch.int32)
+        B, Np = labels.shape
+        sparse, dense = self.new(B, Np + 1, 256), self.new(B, 256, 64, 64)
+        self._check(self.lib.sam2mi_prompt_encoder(self.h, self.stream, _ptr(coords), _ptr(labels), B, Np, _ptr(sparse), _ptr(dense)),
+                    "sam2mi_prompt_encoder")
+        return sparse, dense
+
+    def dense_pe(self):
+        out = self.new(1, 256, 64, 64)
+        self._check(self.lib.sam2mi_dense_pe(self.h, self.stream, _ptr(out)), "sam2mi_dense_pe")
+        return out
+
+    def resize_bilinear(self, x: torch.Tensor, size):
+        x = x.contiguous()
+        _chk_f32(x)
+        lead = x.shape[:-2]
+        Cn = int(np.prod(lead)) if len(lead) else 1
+        out = self.new(*lead, size[0], size[1])
+        self._check(self.lib.sam2mi_resize_bilinear(self.h, self.stream, _ptr(x), Cn, x.shape[-2], x.shape[-1], _ptr(out),
+                                                    size[0], size[1]), "sam2mi_resize_bilinear")
+        return out
+
+    # ------------------------------------------------------------------ fused video path
+    def video_encode(self, frames: torch.Tensor, feat_slots: Sequence[int]):
+        _chk_f32(frames)
+        B = frames.shape[0]
+        sl = (C.c_int32 * B)(*feat_slots)
+        self._check(self.lib.sam2mi_video_encode(self.h, self.stream, _ptr(frames), B, sl), "sam2mi_video_encode")
+
+    def _frame_out(self, want: dict) -> FrameOut:
+        fo = FrameOut()
+        for k, t in want.items():
+            setattr(fo, k, t.data_ptr() if t is not None else None)
+        return fo
+
+    def video_click(self, feat_slot: int, coords: np.ndarray, labels: np.ndarray, multimask: bool, bank_slot: int, outs: dict):
+        coords = np.ascontiguousarray(coords, np.float32).reshape(-1, 2)
+        labels = np.ascontiguousarray(labels, np.int32).reshape(-1)
+        fo = self._frame_out(outs)
+        self._check(self.lib.sam2mi_video_click(self.h, self.stream, feat_slot, coords.ctypes.data_as(C.c_void_p),
+                                                labels.ctypes.data_as(C.c_void_p), len(labels), int(multimask), bank_slot,
+                                                C.byref(fo)), "sam2mi_video_click")
+
+    def video_encode_memory(self, feat_slot: int, bank_slot: int, is_mask_from_pts: bool):
+        self._check(self.lib.sam2mi_video_encode_memory(self.h, self.stream, feat_slot, bank_slot, int(is_mask_from_pts)),
+                    "sam2mi_video_encode_memory")
+
+    def video_track(self, feat_slot: int, sel: MemSelect, bank_slot: int, run_mem_encoder: bool, outs: dict):
+        fo = self._frame_out(outs)
+        self._check(self.lib.sam2mi_video_track(self.h, self.stream, feat_slot, C.byref(sel), bank_slot, int(run_mem_encoder),
+                                                C.byref(fo)), "sam2mi_video_track")
+
+    # ------------------------------------------------------------------ profiling
+    def profile_enable(self, on: bool):
+        self._check(self.lib.sam2mi_profile_enable(self.h, int(on)), "sam2mi_profile_enable")
+
+    def profile_read(self) -> dict:
+        v = [C.c_double(), C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_int64()]
+        self._check(self.lib.sam2mi_profile_read(self.h, *[C.byref(x) for x in v]), "sam2mi_profile_read")
+        return dict(gemm_ms=v[0].value, gemm_flops=v[1].value, gemm_launches=v[2].value, attn_ms=v[3].value,
+                    attn_flops=v[4].value, attn_launches=v[5].value)
+
+    # ------------------------------------------------------------------ single-kernel debug entry points (tests)
+    def debug_gemm(self, A, W, bias=None, act=0, residual=None):
+        M, K = A.shape
+        N = W.shape[0]
+        out = self.new(M, N)
+        self._check(self.lib.sam2mi_debug_gemm(self.h, self.stream, _ptr(A.contiguous()), _ptr(W.contiguous()), _ptr(bias), M, N, K,
+                                               act, _ptr(residual), _ptr(out)), "sam2mi_debug_gemm")
+        return out
+
+    def debug_hiera_attention(self, q, k, v, groups, heads, GQ, GK, wq, wk):
+        out = self.new(*q.shape)
+        self._check(self.lib.sam2mi_debug_hiera_attention(self.h, self.stream, _ptr(q.contiguous()), _ptr(k.contiguous()),
+                                                          _ptr(v.contiguous()), groups, heads, GQ, GK, wq, wk, _ptr(out)),
+                    "sam2mi_debug_hiera_attention")
+        return out
+
+    def debug_flash256(self, q, k, v):
+        out = self.new(*q.shape)
+        self._check(self.lib.sam2mi_debug_flash256(self.h, self.stream, _ptr(q.contiguous()), _ptr(k.contiguous()),
+                                                   _ptr(v.contiguous()), q.shape[0], k.shape[0], _ptr(out)), "sam2mi_debug_flash256")
+        return out
+
+    def debug_hiera_block(self, idx: int, x_nhwc: torch.Tensor, out_shape):
+        out = self.new(*out_shape)
+        self._check(self.lib.sam2mi_debug_hiera_block(self.h, self.stream, idx, _ptr(x_nhwc.contiguous()), x_nhwc.shape[0], _ptr(out)),
+                    "sam2mi_debug_hiera_block")
+        return out
+
+    def debug_read(self, name: str, *shape):
+        out = self.new(*shape)
+        self._check(self.lib.sam2mi_debug_read(self.h, self.stream, name.encode(), _ptr(out), C.c_int64(out.numel())), "sam2mi_debug_read")
+        return out

@@ -1,0 +1,332 @@
+"""SAM2VideoPredictor on the MI355X-native backend.
+
+Host-side mirror of the reference predictor's interface and state machine
+(/root/reference/sam2/sam2/sam2_video_predictor_official.py: init_state :147-205,
+add_new_points_or_box :266-399, propagate_in_video_preflight :585-649, propagate_in_video :651-736,
+_run_single_frame_inference :843-909) and of SAM2Base._prepare_memory_conditioned_features
+(modeling/sam2_base_official.py:797-976, the memory / object-pointer selection).  All tensor work is
+done by libsam2mi.so through sam2_opt_amd.native.Engine: frame features and the memory bank stay
+resident in HBM, the host only passes slot indices - there is no per-frame host<->device sync.
+
+Differences from the reference, all deliberate:
+  * the image encoder runs on batches of upcoming frames (`encode_batch`), since it does not depend on
+    the tracking state; the reference encodes one frame at a time;
+  * `fill_hole_area` defaults to 0: the reference's hole filling needs its CUDA extension and is silently
+    skipped without it (utils/misc.py:321-336);
+  * mask prompts (`add_new_mask`) and correction clicks on already-tracked frames are not implemented yet.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .config import get_config
+from .native import Engine, MemSelect
+from .synthetic import normalize_frames
+
+
+class SAM2VideoPredictor:
+    def __init__(self, model: str = "large", state_dict=None, ckpt_path: Optional[str] = None, device=None,
+                 encode_batch: int = 8, bank_slots: int = 96, fill_hole_area: int = 0, non_overlap_masks: bool = False):
+        self.cfg = get_config(model)
+        if state_dict is None and ckpt_path is not None:
+            # same contract as build_sam._load_checkpoint (build_sam.py:164-174)
+            state_dict = torch.load(ckpt_path, map_location="cpu", weights_only=True)["model"]
+        if state_dict is None:
+            raise ValueError("state_dict or ckpt_path is required")
+        self.encode_batch = int(encode_batch)
+        self.engine = Engine(self.cfg, state_dict=state_dict, max_batch=self.encode_batch, bank_slots=bank_slots,
+                             feat_slots=max(2 * self.encode_batch, 4), device=device)
+        self.device = self.engine.device
+        self.image_size = self.cfg["image_size"]
+        self.num_maskmem = self.cfg["num_maskmem"]
+        self.max_obj_ptrs_in_encoder = self.cfg["max_obj_ptrs_in_encoder"]
+        self.fill_hole_area = fill_hole_area
+        self.non_overlap_masks = non_overlap_masks
+        if fill_hole_area > 0:
+            raise NotImplementedError("connected-component hole filling is not implemented on this backend yet")
+        self.backend = "hip"
+        self.debug_trace = None      # set to {} to record per-frame intermediates (parity tests)
+
+    # ------------------------------------------------------------------ backend switch (reference: speedup :45-145)
+    def speedup(self, backend: str = "hip", use_cache: bool = True, model_root_path=None):
+        if backend not in ("hip", "mi355x", "sam2mi"):
+            raise RuntimeError(f"Unknown backend={backend}: this predictor only runs the MI355X HIP backend "
+                               "(attach sam2_opt_amd.plugin to the reference predictor to switch per plug)")
+        self.backend = "hip"
+
+    def release(self):
+        self.engine.close()
+
+    # ------------------------------------------------------------------ state
+    @torch.inference_mode()
+    def init_state(self, video_path=None, frames: Optional[torch.Tensor] = None, video_height: Optional[int] = None,
+                   video_width: Optional[int] = None, offload_video_to_cpu: bool = False, **_unused):
+        """`frames`: float32 (T,3,1024,1024) already /255 and mean/std normalised (what load_video_frames returns),
+        on CPU or GPU; or `video_path`: a folder of JPEGs (needs PIL)."""
+        if frames is None:
+            frames, video_height, video_width = _load_jpeg_folder(video_path, self.cfg)
+        if not offload_video_to_cpu:
+            frames = frames.to(self.device)
+        st = {
+            "images": frames, "num_frames": frames.shape[0],
+            "video_height": video_height or self.image_size, "video_width": video_width or self.image_size,
+            "device": self.device, "offload_video_to_cpu": offload_video_to_cpu,
+            "point_inputs_per_obj": {}, "obj_id_to_idx": OrderedDict(), "obj_idx_to_id": OrderedDict(), "obj_ids": [],
+            "output_dict_per_obj": {}, "temp_output_dict_per_obj": {}, "frames_tracked_per_obj": {},
+            "feat_slot_of_frame": OrderedDict(), "free_feat_slots": list(range(self.engine.feat_slots)),
+            "free_bank_slots": list(range(self.engine.bank_slots)),
+        }
+        self._ensure_features(st, 0, forward=True)       # warm up the backbone like the reference (:204)
+        return st
+
+    def reset_state(self, st):
+        for d in list(st["output_dict_per_obj"].values()) + list(st["temp_output_dict_per_obj"].values()):
+            for k in ("cond_frame_outputs", "non_cond_frame_outputs"):
+                for out in d[k].values():
+                    self._free_bank(st, out)
+                d[k].clear()
+        for k in ("point_inputs_per_obj", "obj_id_to_idx", "obj_idx_to_id", "output_dict_per_obj",
+                  "temp_output_dict_per_obj", "frames_tracked_per_obj"):
+            st[k].clear()
+        st["obj_ids"] = []
+
+    def _obj_id_to_idx(self, st, obj_id):
+        idx = st["obj_id_to_idx"].get(obj_id)
+        if idx is not None:
+            return idx
+        idx = len(st["obj_id_to_idx"])
+        st["obj_id_to_idx"][obj_id] = idx
+        st["obj_idx_to_id"][idx] = obj_id
+        st["obj_ids"] = list(st["obj_id_to_idx"])
+        st["point_inputs_per_obj"][idx] = {}
+        st["output_dict_per_obj"][idx] = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+        st["temp_output_dict_per_obj"][idx] = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
+        st["frames_tracked_per_obj"][idx] = {}
+        return idx
+
+    # ------------------------------------------------------------------ slots
+    def _alloc_bank(self, st) -> int:
+        if not st["free_bank_slots"]:
+            raise RuntimeError("memory bank exhausted: raise bank_slots")
+        return st["free_bank_slots"].pop()
+
+    def _free_bank(self, st, out):
+        if out is not None and out.get("slot") is not None:
+            st["free_bank_slots"].append(out["slot"])
+            out["slot"] = None
+
+    def _ensure_features(self, st, frame_idx: int, forward: bool = True) -> int:
+        """Feature-cache slot of `frame_idx`; on a miss encode a batch of frames starting there
+        (cf. _get_image_feature :810-841, which caches exactly one frame)."""
+        m = st["feat_slot_of_frame"]
+        if frame_idx in m:
+            return m[frame_idx]
+        T = st["num_frames"]
+        step = 1 if forward else -1
+        idxs = [t for t in range(frame_idx, frame_idx + step * self.encode_batch, step) if 0 <= t < T and t not in m]
+        while len(st["free_feat_slots"]) < len(idxs):          # evict the oldest cached frames
+            _, sl = m.popitem(last=False)
+            st["free_feat_slots"].append(sl)
+        slots = [st["free_feat_slots"].pop() for _ in idxs]
+        imgs = st["images"][idxs] if len(idxs) > 1 else st["images"][idxs[0]:idxs[0] + 1]
+        imgs = imgs.to(self.device, dtype=torch.float32).contiguous()
+        self.engine.video_encode(imgs, slots)
+        for t, sl in zip(idxs, slots):
+            m[t] = sl
+        return m[frame_idx]
+
+    # ------------------------------------------------------------------ prompts
+    @torch.inference_mode()
+    def add_new_points_or_box(self, inference_state, frame_idx, obj_id, points=None, labels=None, clear_old_points=True,
+                              normalize_coords=True, box=None):
+        st = inference_state
+        obj_idx = self._obj_id_to_idx(st, obj_id)
+        if (points is not None) != (labels is not None):
+            raise ValueError("points and labels must be provided together")
+        if points is None and box is None:
+            raise ValueError("at least one of points or box must be provided as input")
+        pts = np.zeros((0, 2), np.float32) if points is None else np.asarray(points, np.float32).reshape(-1, 2)
+        lab = np.zeros((0,), np.int32) if labels is None else np.asarray(labels, np.int32).reshape(-1)
+        if box is not None:
+            if not clear_old_points:
+                raise ValueError("cannot add box without clearing old points, since box prompt must be provided "
+                                 "before any point prompt (please use clear_old_points=True instead)")
+            pts = np.concatenate([np.asarray(box, np.float32).reshape(2, 2), pts], axis=0)
+            lab = np.concatenate([np.array([2, 3], np.int32), lab], axis=0)
+        if normalize_coords:
+            pts = pts / np.array([st["video_width"], st["video_height"]], np.float32)
+        pts = pts * self.image_size
+        per_frame = st["point_inputs_per_obj"][obj_idx]
+        if not clear_old_points and frame_idx in per_frame:
+            pts = np.concatenate([per_frame[frame_idx][0], pts], axis=0)
+            lab = np.concatenate([per_frame[frame_idx][1], lab], axis=0)
+        per_frame[frame_idx] = (pts, lab)
+        if frame_idx in st["frames_tracked_per_obj"][obj_idx]:
+            raise NotImplementedError("correction clicks on an already tracked frame are not implemented yet")
+        temp = st["temp_output_dict_per_obj"][obj_idx]["cond_frame_outputs"]
+        self._free_bank(st, temp.pop(frame_idx, None))
+        feat = self._ensure_features(st, frame_idx)
+        slot = self._alloc_bank(st)
+        n = len(lab)
+        multimask = self.cfg["multimask_min_pt_num"] <= n <= self.cfg["multimask_max_pt_num"]    # _use_multimask :1181-1189
+        low = self.engine.new(1, 1, 256, 256)
+        score = self.engine.new(1, 1)
+        self.engine.video_click(feat, pts, lab, multimask, slot, dict(low_res_masks=low, object_score_logits=score))
+        temp[frame_idx] = dict(slot=slot, pred_masks=low, object_score_logits=score, has_mem=False, is_pts=True)
+        return frame_idx, st["obj_ids"], self._video_res(st, self._consolidated(st, frame_idx))
+
+    def add_new_points(self, *a, **k):
+        return self.add_new_points_or_box(*a, **k)
+
+    def add_new_mask(self, *a, **k):
+        raise NotImplementedError("mask prompts are not implemented on this backend yet")
+
+    def _consolidated(self, st, frame_idx):
+        """(num_obj,1,256,256) low-res logits on `frame_idx`; objects without output get NO_OBJ_SCORE (:525-570)."""
+        outs = []
+        for obj_idx in range(len(st["obj_ids"])):
+            out = None
+            for d in (st["temp_output_dict_per_obj"][obj_idx], st["output_dict_per_obj"][obj_idx]):
+                for k in ("cond_frame_outputs", "non_cond_frame_outputs"):
+                    out = out or d[k].get(frame_idx)
+            outs.append(out["pred_masks"] if out is not None else torch.full((1, 1, 256, 256), -1024.0, device=self.device))
+        return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+
+    def _video_res(self, st, low):
+        H, W = st["video_height"], st["video_width"]
+        if low.shape[-2:] == (H, W):
+            return low
+        return self.engine.resize_bilinear(low, (H, W))
+
+    # ------------------------------------------------------------------ propagation
+    @torch.inference_mode()
+    def propagate_in_video_preflight(self, inference_state):
+        st = inference_state
+        if len(st["obj_ids"]) == 0:
+            raise RuntimeError("No input points or masks are provided for any object; please add inputs first.")
+        for obj_idx in range(len(st["obj_ids"])):
+            od, td = st["output_dict_per_obj"][obj_idx], st["temp_output_dict_per_obj"][obj_idx]
+            for key in ("non_cond_frame_outputs", "cond_frame_outputs"):
+                for t, out in td[key].items():
+                    if not out["has_mem"]:
+                        # memory encoder on the interacted frame, binarised mask (:610-627, sam2_base :1000-1010)
+                        self.engine.video_encode_memory(self._ensure_features(st, t), out["slot"], True)
+                        out["has_mem"] = True
+                    self._free_bank(st, od[key].get(t))
+                    od[key][t] = out
+                td[key].clear()
+            if len(od["cond_frame_outputs"]) == 0:
+                raise RuntimeError(f"No input points or masks are provided for object id {st['obj_idx_to_id'][obj_idx]}; "
+                                   "please add inputs first.")
+            for t in od["cond_frame_outputs"]:
+                self._free_bank(st, od["non_cond_frame_outputs"].pop(t, None))
+
+    def _select_memory(self, od, frame_idx: int, num_frames: int, reverse: bool) -> MemSelect:
+        """SAM2Base._prepare_memory_conditioned_features step 1 (sam2_base_official.py:823-946)."""
+        sel = MemSelect()
+        cond, non_cond = od["cond_frame_outputs"], od["non_cond_frame_outputs"]
+        mems = [(0, out) for out in cond.values()]                   # max_cond_frames_in_attn = -1: all of them
+        for t_pos in range(1, self.num_maskmem):
+            t_rel = self.num_maskmem - t_pos
+            prev = frame_idx + t_rel if reverse else frame_idx - t_rel          # stride 1 (:843-864)
+            mems.append((t_pos, non_cond.get(prev)))
+        n = 0
+        for t_pos, out in mems:
+            if out is None or not out["has_mem"]:
+                continue
+            if n >= 8:
+                raise NotImplementedError("more than 8 spatial memories (too many conditioning frames)")
+            sel.mem_slot[n] = out["slot"]
+            sel.mem_tpos[n] = self.num_maskmem - t_pos - 1
+            n += 1
+        sel.num_mem = n
+        max_ptrs = min(num_frames, self.max_obj_ptrs_in_encoder)
+        sign = -1 if reverse else 1
+        ptrs = [((frame_idx - t) * sign, out) for t, out in cond.items() if (t >= frame_idx if reverse else t <= frame_idx)]
+        for t_diff in range(1, max_ptrs):
+            t = frame_idx + t_diff if reverse else frame_idx - t_diff
+            if t < 0 or t >= num_frames:
+                break
+            out = non_cond.get(t)
+            if out is not None and out["slot"] is not None:
+                ptrs.append((t_diff, out))
+        if len(ptrs) > 32:
+            raise NotImplementedError("more than 32 object pointers")
+        for i, (dt, out) in enumerate(ptrs):
+            sel.ptr_slot[i] = out["slot"]
+            sel.ptr_dt[i] = float(dt)
+        sel.num_ptr = len(ptrs)
+        sel.ptr_tmax = float(max_ptrs - 1)
+        return sel
+
+    def _release_stale(self, st, od, frame_idx: int, reverse: bool):
+        """Bank slots of non-conditioning frames that no later frame can attend to are recycled
+        (the reference keeps them for re-interaction; low-res masks are kept here too)."""
+        horizon = self.max_obj_ptrs_in_encoder + 1
+        for t in [t for t in od["non_cond_frame_outputs"] if (t > frame_idx + horizon if reverse else t < frame_idx - horizon)]:
+            self._free_bank(st, od["non_cond_frame_outputs"][t])
+
+    @torch.inference_mode()
+    def propagate_in_video(self, inference_state, start_frame_idx=None, max_frame_num_to_track=None, reverse=False):
+        st = inference_state
+        self.propagate_in_video_preflight(st)
+        num_frames = st["num_frames"]
+        if start_frame_idx is None:
+            start_frame_idx = min(t for od in st["output_dict_per_obj"].values() for t in od["cond_frame_outputs"])
+        if max_frame_num_to_track is None:
+            max_frame_num_to_track = num_frames
+        if reverse:
+            end = max(start_frame_idx - max_frame_num_to_track, 0)
+            order = range(start_frame_idx, end - 1, -1) if start_frame_idx > 0 else []
+        else:
+            end = min(start_frame_idx + max_frame_num_to_track, num_frames - 1)
+            order = range(start_frame_idx, end + 1)
+        for frame_idx in order:
+            per_obj = []
+            for obj_idx in range(len(st["obj_ids"])):
+                od = st["output_dict_per_obj"][obj_idx]
+                if frame_idx in od["cond_frame_outputs"]:
+                    low = od["cond_frame_outputs"][frame_idx]["pred_masks"]
+                else:
+                    feat = self._ensure_features(st, frame_idx, forward=not reverse)
+                    sel = self._select_memory(od, frame_idx, num_frames, reverse)
+                    self._free_bank(st, od["non_cond_frame_outputs"].pop(frame_idx, None))
+                    slot = self._alloc_bank(st)
+                    low = self.engine.new(1, 1, 256, 256)
+                    score = self.engine.new(1, 1)
+                    outs = dict(low_res_masks=low, object_score_logits=score)
+                    if self.debug_trace is not None:
+                        outs.update(pix_feat=self.engine.new(4096, 1, 256), ious=self.engine.new(1, 3), obj_ptr=self.engine.new(1, 256),
+                                    low_res_multimasks=self.engine.new(1, 3, 256, 256),
+                                    best_idx=self.engine.new(1, dtype=torch.int32))
+                        self.debug_trace[(obj_idx, frame_idx)] = dict(outs, L=sel.num_mem, P=4 * sel.num_ptr)
+                    self.engine.video_track(feat, sel, slot, True, outs)
+                    od["non_cond_frame_outputs"][frame_idx] = dict(slot=slot, pred_masks=low, object_score_logits=score,
+                                                                   has_mem=True, is_pts=False)
+                    self._release_stale(st, od, frame_idx, reverse)
+                st["frames_tracked_per_obj"][obj_idx][frame_idx] = {"reverse": reverse}
+                per_obj.append(low)
+            low_all = torch.cat(per_obj, dim=0) if len(per_obj) > 1 else per_obj[0]
+            yield frame_idx, st["obj_ids"], self._video_res(st, low_all)
+
+
+def _load_jpeg_folder(path, cfg):
+    """load_video_frames_from_jpg_images (utils/misc.py:213-277): PIL resize to 1024^2, /255, mean/std."""
+    import os
+
+    from PIL import Image
+    names = sorted([p for p in os.listdir(path) if os.path.splitext(p)[-1].lower() in (".jpg", ".jpeg")],
+                   key=lambda p: int(os.path.splitext(p)[0]))
+    if not names:
+        raise RuntimeError(f"no images found in {path}")
+    S = cfg["image_size"]
+    frames = np.zeros((len(names), S, S, 3), np.uint8)
+    for i, n in enumerate(names):
+        im = Image.open(os.path.join(path, n))
+        W, H = im.size
+        frames[i] = np.array(im.convert("RGB").resize((S, S)))
+    return normalize_frames(frames, cfg), H, W

@@ -1,0 +1,92 @@
+"""GPU: single HIP kernels through the C ABI (sam2mi_debug_*) vs plain PyTorch fp32 on the same inputs.
+Operands are rounded to f16 on both sides, so the tolerance only has to cover accumulation order."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import check
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from sam2_opt_amd.native import Engine
+    e = Engine("large", state_dict=None, max_batch=1)
+    yield e
+    e.close()
+
+
+def r16(x):
+    return x.half().float()
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [
+    (300, 200, 144, 0, False), (4096, 1728, 576, 0, False), (16384, 432, 144, 1, True), (8, 256, 256, 2, False),
+    (1000, 64, 160, 0, True), (4096, 4, 32, 0, False), (129, 65, 2304, 1, True), (4096, 576, 2304, 0, True),
+])
+def test_gemm(eng, M, N, K, act, res):
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    A = r16(torch.randn(M, K, generator=g)).cuda()
+    W = r16(torch.randn(N, K, generator=g) / math.sqrt(K)).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).cuda() if res else None
+    out = eng.debug_gemm(A, W, b, act, R)
+    ref = A.double() @ W.double().t() + b.double()
+    if act == 1:
+        ref = F.gelu(ref)
+    elif act == 2:
+        ref = F.relu(ref)
+    if res:
+        ref = ref + R.double()
+    check(f"gemm {M}x{N}x{K} act{act}", out, ref.float(), 1e-4, 1e-5)
+
+
+def _ref_attn(q, k, v, groups, heads, GQ, GK, wq, wk):
+    C = heads * 72
+    qh = q.view(groups, GQ, heads, 72).permute(0, 2, 1, 3).double()
+    kh = k.view(groups, GK, heads, 72).permute(0, 2, 1, 3).double()
+    vh = v.view(groups, GK, heads, 72).permute(0, 2, 1, 3).double()
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(72)
+    qi = torch.arange(GQ, device=q.device) // wq
+    ki = torch.arange(GK, device=q.device) // wk
+    mask = qi[:, None] == ki[None, :]
+    s = s.masked_fill(~mask, float("-inf"))
+    o = torch.softmax(s, -1) @ vh
+    return o.permute(0, 2, 1, 3).reshape(groups * GQ, C).float()
+
+
+@pytest.mark.parametrize("groups,heads,GQ,GK,wq,wk", [
+    (6, 2, 64, 64, 64, 64),        # stage-1 8x8 windows
+    (5, 4, 32, 128, 16, 64),       # block 2: pooled queries, 2 windows packed
+    (9, 4, 32, 32, 16, 16),        # stage-2 4x4 windows, 2 packed
+    (3, 8, 32, 128, 4, 16),        # block 8: 8 windows packed
+    (2, 8, 256, 256, 256, 256),    # stage-3 16x16 windows (shared staging)
+    (1, 8, 1024, 1024, 1024, 1024),  # global attention (reduced length)
+    (2, 16, 64, 256, 64, 256),     # block 44
+])
+def test_hiera_attention(eng, groups, heads, GQ, GK, wq, wk):
+    g = torch.Generator(device="cpu").manual_seed(groups * 100 + GQ + GK)
+    C = heads * 72
+    q = r16(torch.randn(groups * GQ, C, generator=g) * 1.5).cuda()
+    k = r16(torch.randn(groups * GK, C, generator=g) * 1.5).cuda()
+    v = r16(torch.randn(groups * GK, C, generator=g)).cuda()
+    out = eng.debug_hiera_attention(q, k, v, groups, heads, GQ, GK, wq, wk)
+    ref = _ref_attn(q, k, v, groups, heads, GQ, GK, wq, wk)
+    check(f"hiera_attn g{groups} h{heads} {GQ}/{GK} w{wq}/{wk}", out, ref, 4e-3, 2e-3)
+
+
+@pytest.mark.parametrize("Nq,Nk", [(128, 32), (256, 4096), (128, 4100), (256, 8204), (128, 28736 + 64)])
+def test_flash256(eng, Nq, Nk):
+    g = torch.Generator(device="cpu").manual_seed(Nq + Nk)
+    q = r16(torch.randn(Nq, 256, generator=g)).cuda()
+    k = r16(torch.randn(Nk, 256, generator=g)).cuda()
+    v = r16(torch.randn(Nk, 256, generator=g)).cuda()
+    # spike one key so that the running max jumps late in the sweep (online-softmax rescale path)
+    k[Nk - 3] = r16(q[5] * 2.0)
+    out = eng.debug_flash256(q, k, v)
+    s = (q.double() @ k.double().t()) / 16.0
+    ref = (torch.softmax(s, -1) @ v.double()).float()
+    check(f"flash256 {Nq}x{Nk}", out, ref, 4e-3, 2e-3)

@@ -28,14 +28,16 @@ def test_video_oracle_matches_reference(sd_large, cfg_large, golden_video):
             ok, msg = compare(g, f"f{t}/video_res_mask", vm, atol=5e-3, rtol=1e-3)
             assert ok, msg
             if t == 0:
-                ok, msg = compare(g, "f0/maskmem_features", vo.cond[0]["maskmem_features"].float(), atol=2e-3, rtol=8e-3)  # 1 bf16 ulp
+                ok, msg = compare(g, "f0/maskmem_features", vo.cond[0]["maskmem_features"].float(), atol=2e-3, rtol=8e-3, outlier_frac=2e-3)  # 1 bf16 ulp; a mask pixel
+                # with logit ~0 may binarise differently (sam2_base_official.py:1000-1004) -> rare local outliers
                 assert ok, msg
                 continue
             tr = vo.trace[("track", t)]
             L, P = (int(v) for v in g[f"f{t}/LP"])
             assert tr["memattn_in"][1].shape[0] == L and tr["memattn_in"][4].shape[0] == P
             for n, x in zip(("curr", "memory", "curr_pos", "memory_pos", "mem_ex", "mem_pos_ex"), tr["memattn_in"]):
-                ok, msg = compare(g, f"f{t}/memattn_in/{n}", x, atol=2e-3, rtol=8e-3 if n in ("memory", "mem_ex") else 1e-3)
+                ok, msg = compare(g, f"f{t}/memattn_in/{n}", x, atol=2e-3, rtol=8e-3 if n in ("memory", "mem_ex") else 1e-3,
+                                      outlier_frac=2e-3 if n == "memory" else 0.0)
                 assert ok, msg
             ok, msg = compare(g, f"f{t}/memattn_out", tr["pix_feat"].flatten(2).permute(2, 0, 1), atol=5e-3, rtol=1e-3)
             assert ok, msg

@@ -1,0 +1,133 @@
+"""GPU: every plug point of the HIP backend (through the C ABI, reference tensor layouts) vs the CPU oracle
+(oracle/sam2_ref.py, itself pinned to the real reference by tests/golden/) on the same seeded inputs and
+synthetic hiera-large weights.  f16 MFMA operands with f32 accumulation: tolerances are stated per plug as
+(max-abs error / max|ref|, relative L2)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import check
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng(sd_large):
+    from sam2_opt_amd.native import Engine
+    e = Engine("large", state_dict=sd_large, max_batch=2)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def oracle_enc(sd_large, cfg_large):
+    from oracle import sam2_ref as R
+    from sam2_opt_amd.synthetic import synthetic_image_normed
+    img = synthetic_image_normed(seed=1)
+    blocks = {i: None for i in (-1, 0, 1, 2, 3, 7, 8, 9, 22, 23, 43, 44, 45, 47)}
+    with torch.inference_mode():
+        outs = R.image_encoder(img, sd_large, cfg_large, blocks)
+    return img, outs, blocks
+
+
+@pytest.mark.parametrize("idx", [0, 2, 3, 8, 9, 23, 44, 45])
+def test_hiera_block(eng, oracle_enc, idx):
+    """One MultiScaleBlock (hieradet.py:134-166) fed with the oracle's input for that block."""
+    _, _, blocks = oracle_enc
+    x = blocks[idx - 1].cuda()
+    ref = blocks[idx]
+    out = eng.debug_hiera_block(idx, x, ref.shape)
+    check(f"hiera block {idx}", out, ref, 5e-3, 2e-3)
+
+
+def test_image_encoder(eng, oracle_enc):
+    img, outs, _ = oracle_enc
+    got = eng.image_encoder(img.cuda())
+    names = ["vision_features", "vision_pos_enc0", "vision_pos_enc1", "vision_pos_enc2", "backbone_fpn0", "backbone_fpn1", "backbone_fpn2"]
+    for n, g, r in zip(names, got, outs):
+        tol = (1e-5, 1e-6) if "pos_enc" in n else (2e-2, 1e-2)
+        check("encoder/" + n, g, r, *tol)
+
+
+def test_image_encoder_batch2_matches_batch1(eng, oracle_enc):
+    img, outs, _ = oracle_enc
+    from sam2_opt_amd.synthetic import synthetic_image_normed
+    img2 = torch.cat([synthetic_image_normed(seed=7), img], dim=0).cuda()
+    got = eng.image_encoder(img2)
+    check("encoder batch2[1] vision_features", got[0][1:2], outs[0], 2e-2, 1e-2)
+    check("encoder batch2[1] fpn0", got[4][1:2], outs[4], 2e-2, 1e-2)
+
+
+def test_set_image_e2e(eng, sd_large, cfg_large):
+    from oracle import sam2_ref as R
+    rs = np.random.RandomState(5)
+    img01 = torch.from_numpy(rs.rand(1, 3, 1024, 1024).astype(np.float32))
+    with torch.inference_mode():
+        ref = R.set_image_e2e(img01, sd_large, cfg_large)
+    got = eng.set_image_e2e(img01.cuda())
+    for n, g, r in zip(("feat0", "feat1", "feat2"), got, ref):
+        check("set_image_e2e/" + n, g, r, 2e-2, 1e-2)
+
+
+@pytest.mark.parametrize("tag", ["memattn_L1P4", "memattn_L3P12", "memattn_L1P0"])
+def test_memory_attention(eng, sd_large, cfg_large, tag):
+    from oracle import sam2_ref as R
+    from oracle.gen_golden import plug_inputs
+    inp = plug_inputs(cfg_large)[tag]
+    with torch.inference_mode():
+        ref = R.memory_attention(*inp, sd_large, cfg_large)
+    got = eng.memory_attention(*[t.cuda() for t in inp])
+    check(tag, got, ref, 5e-3, 2e-3)
+
+
+def test_memory_attention_full_bank(eng, sd_large, cfg_large):
+    """L = 7 frames + 64 pointer tokens (28,736 keys): the steady-state shape of config 3."""
+    from oracle import sam2_ref as R
+    from sam2_opt_amd.synthetic import randn
+    inp = (randn(51, 4096, 1, 256), randn(52, 7, 4096, 1, 64), randn(53, 4096, 1, 256), randn(54, 7, 4096, 1, 64),
+           randn(55, 64, 1, 64), randn(56, 64, 1, 64))
+    with torch.inference_mode():
+        ref = R.memory_attention(*inp, sd_large, cfg_large)
+    got = eng.memory_attention(*[t.cuda() for t in inp])
+    check("memattn_L7P64", got, ref, 5e-3, 2e-3)
+
+
+@pytest.mark.parametrize("tag", ["maskdec_N1T8", "maskdec_N2T15"])
+def test_mask_decoder(eng, sd_large, cfg_large, tag):
+    from oracle import sam2_ref as R
+    from oracle.gen_golden import plug_inputs
+    inp = plug_inputs(cfg_large)[tag]
+    with torch.inference_mode():
+        ref = R.predict_masks(*inp, sd_large, cfg_large)
+    got = eng.mask_decoder(*[t.cuda() for t in inp])
+    fails = []
+    for n, g, r in zip(("masks", "iou", "tokens", "obj"), got, ref):
+        try:
+            check(f"{tag}/{n}", g, r, 1e-2, 5e-3)
+        except AssertionError as e:
+            fails.append(str(e))
+    assert not fails, fails
+
+
+def test_memory_encoder(eng, sd_large, cfg_large):
+    from oracle import sam2_ref as R
+    from oracle.gen_golden import plug_inputs
+    inp = plug_inputs(cfg_large)["memenc"]
+    with torch.inference_mode():
+        x, pos = R.memory_encoder(*inp, sd_large, cfg_large)
+    gx, gpos = eng.memory_encoder(*[t.cuda() for t in inp])
+    check("memenc/x", gx, x, 5e-3, 2e-3)
+    check("memenc/pos", gpos, pos, 1e-5, 1e-6)
+
+
+def test_prompt_encoder(eng, sd_large, cfg_large):
+    from oracle import sam2_ref as R
+    from oracle.gen_golden import plug_inputs
+    pts, lab = plug_inputs(cfg_large)["prompt"]
+    with torch.inference_mode():
+        sp, de = R.prompt_encoder(pts, lab, sd_large, cfg_large)
+        dpe = R.dense_pe(sd_large, cfg_large)
+    gs, gd = eng.prompt_encoder(pts.cuda(), lab.cuda())
+    check("prompt/sparse", gs, sp, 1e-4, 1e-4)
+    check("prompt/dense", gd, de.contiguous(), 1e-6, 1e-6)
+    check("prompt/dense_pe", eng.dense_pe(), dpe, 1e-4, 1e-4)
