@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of SAM2.1-hiera-large 1024x1024 video propagation (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload = BASELINE.json configs[2]/[3]: every GPU tracks its own synthetic 100-frame 1024^2 clip (seed 2 + rank)
+from one positive click on frame 0 with seeded random-init hiera-large weights.  One STEP = one pass of
+`propagate_in_video` over the whole clip (the method of the upstream FPS benchmark,
+/root/reference/sam2/sam2/benchmark.py:71-92: wall time of the propagate loop, frames already on the device,
+fps = frames / time).  W warm-up steps, then K timed steps between barrier + torch.cuda.synchronize();
+time = MAX over ranks; value = N * K * frames / time (weak scaling: independent clips, no data-path collective).
+
+The JSON line also carries
+  roofline     - the dominant kernel (the MFMA GEMM `gemm_f16_kernel`): algorithmic FLOPs / launch time, measured
+                 with HIP events around every GEMM launch on its own stream in a second, un-timed pass of the same
+                 K steps (sam2mi_profile_enable), vs the 2.5 PFLOP/s dense f16 MFMA peak;
+  cpu_baseline - the CPU oracle (oracle/sam2_ref.py, a port of the reference's torch backend) timed on this
+                 box's host cores on the first frames of the same clip (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F16_TFLOPS = 2500.0                 # dense f16/bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
+CLIP_GFLOP_PROPAGATE = 240450.0          # algorithmic GFLOP of one 100-frame propagate loop
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=100)
+    ap.add_argument("--encode-batch", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the clip timed on the CPU oracle")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+
+    from sam2_opt_amd.config import get_config
+    from sam2_opt_amd.synthetic import normalize_frames, synthetic_frames_u8
+    from sam2_opt_amd.video_predictor import SAM2VideoPredictor
+    from sam2_opt_amd.weights import synthetic_state_dict
+
+    cfg = get_config("large")
+    sd = synthetic_state_dict(cfg, seed=0)
+    pred = SAM2VideoPredictor("large", state_dict=sd, encode_batch=args.encode_batch, device=torch.device("cuda", local_rank))
+    frames_u8 = synthetic_frames_u8(seed=2 + rank, num_frames=args.frames)
+    frames = normalize_frames(frames_u8, cfg)
+    state = pred.init_state(frames=frames, video_height=1024, video_width=1024)       # frames resident in HBM from here on
+    pred.add_new_points_or_box(state, 0, 1, points=np.array([[512.0, 512.0]], np.float32), labels=np.array([1], np.int32))
+
+    def one_step():
+        n, chk = 0, None
+        for _, _, masks in pred.propagate_in_video(state):
+            n += 1
+            chk = masks
+        return n, chk
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    nframes = 0
+    last = None
+    for _ in range(args.steps):
+        n, last = one_step()
+        nframes += n
+    barrier()
+    dt = time.perf_counter() - t0
+    checksum = float((last > 0).float().mean().item())
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        # the trivial result gather: (frames, seconds, mask checksum) per rank
+        mine = torch.tensor([nframes, dt, checksum], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        total_frames = int(sum(int(x[0].item()) for x in allr))
+    else:
+        total_frames = nframes
+    value = total_frames / dt
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        pred.engine.profile_enable(True)
+        for _ in range(args.steps):
+            one_step()
+        torch.cuda.synchronize()
+        pr = pred.engine.profile_read()
+        pred.engine.profile_enable(False)
+        ach = pr["gemm_flops"] / (pr["gemm_ms"] * 1e-3) / 1e12 if pr["gemm_ms"] > 0 else 0.0
+        roofline = {
+            "bound": "mfma", "kernel": "gemm_f16_kernel", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
+            "launches": int(pr["gemm_launches"]), "gflop_per_launch": round(pr["gemm_flops"] / max(pr["gemm_launches"], 1) / 1e9, 3),
+            "avg_launch_us": round(pr["gemm_ms"] * 1e3 / max(pr["gemm_launches"], 1), 2),
+            "gemm_share_of_timed_region": round(pr["gemm_ms"] * 1e-3 / dt, 3),
+            "attention_kernels": {"achieved": round(pr["attn_flops"] / max(pr["attn_ms"] * 1e-3, 1e-9) / 1e12, 2),
+                                  "launches": int(pr["attn_launches"]), "ms": round(pr["attn_ms"], 2)},
+            "whole_path": {"algorithmic_gflop_per_step": CLIP_GFLOP_PROPAGATE * args.frames / 100.0,
+                           "achieved_tflops": round(CLIP_GFLOP_PROPAGATE * args.frames / 100.0 * args.steps / 1e3 / dt, 2)},
+        }
+        roofline["whole_path"]["frac_of_mfma_peak"] = round(roofline["whole_path"]["achieved_tflops"] / PEAK_F16_TFLOPS, 4)
+
+    cpu_baseline = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        from oracle import sam2_ref as R         # the checker, timed as the CPU baseline ("port")
+        ncpu = max(2, min(args.cpu_frames, args.frames))
+        cores = torch.get_num_threads()
+        vo = R.VideoOracle(sd, cfg, frames.cpu())
+        with torch.inference_mode():
+            vo.add_new_points(0, np.array([[512.0, 512.0]], np.float32), np.array([1], np.int32))
+            t1 = time.perf_counter()
+            k = 0
+            for _t, _m in vo.propagate(max_frames=ncpu - 1):
+                k += 1
+            cdt = time.perf_counter() - t1
+        cpu_baseline = {"value": round(k / cdt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+                        "sample": f"propagate loop over the first {k} frames of the same clip (fp32, torch CPU kernels, "
+                                  f"memory bank still growing: L<={k - 1}); {cdt:.1f} s"}
+
+    if rank == 0:
+        out = {
+            "metric": "frames/sec SAM2.1-hiera-large 1024x1024 video propagation", "value": round(value, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"config3: {args.frames}-frame 1024x1024 clip per GPU, 1 click, 1 object, SAM2.1-hiera-large "
+                                   "(random-init weights), propagate_in_video loop", "frames_per_step": args.frames,
+                       "encode_batch": args.encode_batch, "parallelism": f"clips x{world} (one process per GPU)",
+                       "ms_per_frame": round(dt / max(nframes, 1) * 1e3, 3), "mask_checksum": round(checksum, 6)},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
