@@ -150,6 +150,7 @@ int sam2mi_debug_hiera_attention(sam2mi_ctx* ctx, void* stream, const float* q, 
                                  int heads, int GQ, int GK, int wq, int wk, float* out);
 int sam2mi_debug_flash256(sam2mi_ctx* ctx, void* stream, const float* q, const float* k, const float* v, int Nq, int Nk, float* out);
 int sam2mi_debug_hiera_block(sam2mi_ctx* ctx, void* stream, int block_idx, const float* x_nhwc, int B, float* out_nhwc);
+int sam2mi_debug_gemm_bench(sam2mi_ctx* ctx, void* stream, int M, int N, int K, int iters, int mode, float* ms_out);
 int sam2mi_debug_read(sam2mi_ctx* ctx, void* stream, const char* name, float* out, int64_t count);
 
 #ifdef __cplusplus

@@ -47,6 +47,108 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const float* __restrict
     if (lane == 0) op[d] = r / L;
   }
 }
+
+// ---- token -> image attention: few queries (T <= 64), 4096+ keys, head_dim 16.
+// One 1024-thread workgroup per (query, head): 16 waves sweep 1/16 of the keys each with float4 loads,
+// their online-softmax states are merged through LDS.
+__global__ __launch_bounds__(1024) void t2i_attn_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                        const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo,
+                                                        int Tq, int Tk, int heads) {
+  constexpr int HD = 16;
+  __shared__ float sm[16], sl[16], so[16][HD];
+  const int qi = blockIdx.x % Tq, h = blockIdx.x / Tq;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  f32x4 qr[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) qr[d] = *reinterpret_cast<const f32x4*>(q + (size_t)qi * ldq + h * HD + 4 * d);
+  float m = -1e30f, l = 0.f, o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+  for (int j = tid; j < Tk; j += 1024) {
+    const float* kp = k + (size_t)j * ldk + h * HD;
+    const float* vp = v + (size_t)j * ldv + h * HD;
+    float s = 0.f;
+    f32x4 vv[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 4 * d);
+      vv[d] = *reinterpret_cast<const f32x4*>(vp + 4 * d);
+      s += qr[d][0] * kk[0] + qr[d][1] * kk[1] + qr[d][2] * kk[2] + qr[d][3] * kk[3];
+    }
+    s *= 0.25f;                                   // 1 / sqrt(16)
+    const float mn = fmaxf(m, s);
+    const float a = __expf(m - mn), pj = __expf(s - mn);
+    l = l * a + pj;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = o[d] * a + pj * vv[d >> 2][d & 3];
+    m = mn;
+  }
+  const float mw = wave_max(m);
+  const float w = __expf(m - mw);
+  const float lw = wave_sum(l * w);
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    const float r = wave_sum(o[d] * w);
+    if (lane == 0) so[wave][d] = r;
+  }
+  if (lane == 0) { sm[wave] = mw; sl[wave] = lw; }
+  __syncthreads();
+  if (tid < HD) {
+    float ms = -1e30f;
+    for (int i = 0; i < 16; ++i) ms = fmaxf(ms, sm[i]);
+    float L = 0.f, acc = 0.f;
+    for (int i = 0; i < 16; ++i) {
+      const float ww = __expf(sm[i] - ms);
+      L += ww * sl[i];
+      acc += ww * so[i][tid];
+    }
+    out[(size_t)qi * ldo + h * HD + tid] = acc / L;
+  }
+}
+
+// ---- image -> token attention: 4096 queries, few keys (Tk <= 64), head_dim 16: one thread per (query, head),
+// keys/values of the head broadcast from LDS.
+__global__ __launch_bounds__(256) void i2t_attn_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                       const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo,
+                                                       int Tq, int Tk, int heads) {
+  constexpr int HD = 16;
+  __shared__ float sk[64 * 128], sv[64 * 128];           // [Tk][heads*HD], heads*HD <= 128
+  const int C = heads * HD;
+  for (int i = threadIdx.x; i < Tk * C; i += 256) {
+    sk[i] = k[(size_t)(i / C) * ldk + i % C];
+    sv[i] = v[(size_t)(i / C) * ldv + i % C];
+  }
+  __syncthreads();
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Tq * heads) return;
+  const int h = idx % heads, qi = idx / heads;
+  f32x4 qr[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) qr[d] = *reinterpret_cast<const f32x4*>(q + (size_t)qi * ldq + h * HD + 4 * d);
+  float m = -1e30f, l = 0.f, o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+  for (int j = 0; j < Tk; ++j) {
+    const float* kp = sk + j * C + h * HD;
+    const float* vp = sv + j * C + h * HD;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) s += qr[d >> 2][d & 3] * kp[d];
+    s *= 0.25f;
+    const float mn = fmaxf(m, s);
+    const float a = __expf(m - mn), pj = __expf(s - mn);
+    l = l * a + pj;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = o[d] * a + pj * vp[d];
+    m = mn;
+  }
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const f32x4 r = {o[4 * d] * inv, o[4 * d + 1] * inv, o[4 * d + 2] * inv, o[4 * d + 3] * inv};
+    *reinterpret_cast<f32x4*>(out + (size_t)qi * ldo + h * HD + 4 * d) = r;
+  }
+}
 }  // namespace
 
 hipError_t small_attn_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
@@ -54,6 +156,15 @@ hipError_t small_attn_launch(const float* q, int ldq, const float* k, int ldk, c
                              size_t o_bstride, hipStream_t stream) {
   const long tasks = (long)batch * heads * Tq;
   const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
+  const bool al = !(ldq & 3) && !(ldk & 3) && !(ldv & 3) && !(ldo & 3);
+  if (hd == 16 && batch == 1 && al && Tq <= 64 && Tk >= 1024) {
+    t2i_attn_kernel<<<dim3(Tq * heads), dim3(1024), 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, Tq, Tk, heads);
+    return hipGetLastError();
+  }
+  if (hd == 16 && batch == 1 && al && Tk <= 64 && heads * 16 <= 128 && Tq >= 1024) {
+    i2t_attn_kernel<<<dim3((Tq * heads + 255) / 256), dim3(256), 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, Tq, Tk, heads);
+    return hipGetLastError();
+  }
   if (hd == 16)
     small_attn_kernel<16><<<grid, block, 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, Tq, Tk, heads, batch, q_bstride, kv_bstride, o_bstride);
   else if (hd == 32)

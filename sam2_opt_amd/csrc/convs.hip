@@ -86,24 +86,31 @@ __global__ void im2col3x3s2_kernel(const half_t* __restrict__ in, int Hin, int C
   *reinterpret_cast<half8*>(A + (size_t)pix * 9 * CIN + k) = v;
 }
 
-__global__ void dwconv7_kernel(const float* __restrict__ in, int H, int C, const float* __restrict__ w, const float* __restrict__ b,
-                               float* __restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)H * H * C) return;
-  const int c = (int)(i % C);
-  const int pix = (int)(i / C);
-  const int y = pix / H, x = pix % H;
-  float acc = b[c];
-  for (int ky = 0; ky < 7; ++ky) {
-    const int iy = y - 3 + ky;
-    if (iy < 0 || iy >= H) continue;
-    for (int kx = 0; kx < 7; ++kx) {
-      const int ix = x - 3 + kx;
-      if (ix < 0 || ix >= H) continue;
-      acc += in[((size_t)iy * H + ix) * C + c] * w[c * 49 + ky * 7 + kx];
-    }
+// depth-wise 7x7: one workgroup = an 8x8 pixel tile x 64 channels; the 14x14 halo patch is staged in LDS
+// (channel innermost, so global reads are 256-B rows and LDS reads are conflict-free across lanes = channels).
+__global__ __launch_bounds__(256) void dwconv7_kernel(const float* __restrict__ in, int H, int C, const float* __restrict__ w,
+                                                      const float* __restrict__ b, float* __restrict__ out) {
+  __shared__ float tile[14 * 14 * 64];
+  __shared__ float sw[49 * 64];
+  const int c0 = blockIdx.z * 64, ty0 = blockIdx.y * 8, tx0 = blockIdx.x * 8;
+  const int lane_c = threadIdx.x & 63, grp = threadIdx.x >> 6;         // 4 pixel groups
+  for (int i = threadIdx.x; i < 14 * 14 * 64; i += 256) {
+    const int c = i & 63, p = i >> 6, py = p / 14, px = p % 14;
+    const int iy = ty0 - 3 + py, ix = tx0 - 3 + px;
+    tile[i] = (iy >= 0 && iy < H && ix >= 0 && ix < H) ? in[((size_t)iy * H + ix) * C + c0 + c] : 0.f;
   }
-  out[i] = acc;
+  for (int i = threadIdx.x; i < 49 * 64; i += 256) sw[i] = w[(size_t)(c0 + (i & 63)) * 49 + (i >> 6)];
+  __syncthreads();
+  const float bias = b[c0 + lane_c];
+  for (int p = grp; p < 64; p += 4) {
+    const int oy = p >> 3, ox = p & 7;
+    float acc = bias;
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) acc += tile[((oy + ky) * 14 + ox + kx) * 64 + lane_c] * sw[(ky * 7 + kx) * 64 + lane_c];
+    out[((size_t)(ty0 + oy) * H + tx0 + ox) * C + c0 + lane_c] = acc;
+  }
 }
 }  // namespace
 
@@ -135,7 +142,7 @@ hipError_t im2col3x3s2_launch(const half_t* in, int Hin, int CIN, half_t* A, hip
 }
 
 hipError_t dwconv7_launch(const float* in, int H, int C, const float* w, const float* b, float* out, hipStream_t s) {
-  const size_t total = (size_t)H * H * C;
-  dwconv7_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(in, H, C, w, b, out);
+  if (H % 8 || C % 64) return hipErrorInvalidValue;
+  dwconv7_kernel<<<dim3(H / 8, H / 8, C / 64), dim3(256), 0, s>>>(in, H, C, w, b, out);
   return hipGetLastError();
 }

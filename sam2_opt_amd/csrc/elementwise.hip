@@ -1,9 +1,78 @@
 // Memory-bound helper kernels of the image encoder and the glue around the GEMMs.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace {
 
-// ------------------------------------------------------------------ LayerNorm: one wave per row
+// ------------------------------------------------------------------ LayerNorm
+// One wave per row, the row held in registers (VPL float4 per lane): a single global read, two wave
+// reductions (mean, then centred variance - the two-pass form PyTorch uses), packed 8-B f16 stores.
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float eps, int M, int C,
+                                                            half_t* y16, int ldy16, float* y32, int ldy32, int act) {
+  const int lane = threadIdx.x & 63;
+  const int nv = C >> 2;                                   // float4 per row
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  f32x4 wv[VPL], bv[VPL];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int v = lane + 64 * k;
+    if (v < nv) {
+      wv[k] = *reinterpret_cast<const f32x4*>(w + 4 * v);
+      bv[k] = *reinterpret_cast<const f32x4*>(b + 4 * v);
+    }
+  }
+  for (int row = wave_global; row < M; row += nwaves) {
+    const float* xr = x + (size_t)row * ldx;
+    f32x4 xv[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int v = lane + 64 * k;
+      if (v < nv) {
+        xv[k] = *reinterpret_cast<const f32x4*>(xr + 4 * v);
+        s += (xv[k][0] + xv[k][1]) + (xv[k][2] + xv[k][3]);
+      }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int v = lane + 64 * k;
+      if (v < nv) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = xv[k][e] - mean;
+          q += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int v = lane + 64 * k;
+      if (v < nv) {
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = (xv[k][e] - mean) * rstd * wv[k][e] + bv[k][e];
+          if (act == 1) t = gelu_erf(t);
+          y[e] = t;
+        }
+        if (y16) {
+          const half4 h = {(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
+          *reinterpret_cast<half4*>(y16 + (size_t)row * ldy16 + 4 * v) = h;
+        }
+        if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)row * ldy32 + 4 * v) = y;
+      }
+    }
+  }
+}
+
+// generic fallback (any C / alignment)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                         const float* __restrict__ b, float eps, int M, int C,
                                                         half_t* y16, int ldy16, float* y32, int ldy32, int act) {
@@ -26,6 +95,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (y16) y16[(size_t)row * ldy16 + c] = (half_t)y;
     if (y32) y32[(size_t)row * ldy32 + c] = y;
   }
+}
+
+// y = f16/f32(a + sb * b): 4 elements per thread when everything is 4-aligned
+__global__ void cast_add_vec_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int bmod,
+                                    float sb, int M, int C4, half_t* y16, int ldy16, float* y32, int ldy32) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * C4) return;
+  const int m = (int)(i / C4), c = (int)(i % C4) * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(a + (size_t)m * lda + c);
+  if (b) {
+    const f32x4 u = *reinterpret_cast<const f32x4*>(b + (size_t)(bmod ? m % bmod : m) * ldb + c);
+    v[0] += sb * u[0]; v[1] += sb * u[1]; v[2] += sb * u[2]; v[3] += sb * u[3];
+  }
+  if (y16) {
+    const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    *reinterpret_cast<half4*>(y16 + (size_t)m * ldy16 + c) = h;
+  }
+  if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)m * ldy32 + c) = v;
 }
 
 __global__ void cast_add_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int bmod,
@@ -157,12 +244,31 @@ inline dim3 grid1d(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1)
 
 hipError_t layernorm_launch(const float* x, int ldx, const float* w, const float* b, float eps, int M, int C, half_t* y16,
                             int ldy16, float* y32, int ldy32, int act, hipStream_t s) {
-  layernorm_kernel<<<dim3((M + 3) / 4), dim3(256), 0, s>>>(x, ldx, w, b, eps, M, C, y16, ldy16, y32, ldy32, act);
+  const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (!y16 || ldy16 % 4 == 0) && (!y32 || ldy32 % 4 == 0) && C <= 1280 &&
+                   ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)b % 16 == 0);
+  if (vec) {
+    const int nv = C / 4, vpl = (nv + 63) / 64;
+    const int blocks = std::min((M + 3) / 4, 256 * 16);
+#define LN_LAUNCH(V) layernorm_vec_kernel<V><<<dim3(blocks), dim3(256), 0, s>>>(x, ldx, w, b, eps, M, C, y16, ldy16, y32, ldy32, act)
+    if (vpl <= 1) LN_LAUNCH(1);
+    else if (vpl == 2) LN_LAUNCH(2);
+    else if (vpl == 3) LN_LAUNCH(3);
+    else LN_LAUNCH(5);
+#undef LN_LAUNCH
+  } else {
+    layernorm_kernel<<<dim3((M + 3) / 4), dim3(256), 0, s>>>(x, ldx, w, b, eps, M, C, y16, ldy16, y32, ldy32, act);
+  }
   return hipGetLastError();
 }
 hipError_t cast_add_launch(const float* a, int lda, const float* b, int ldb, int bmod, float sb, int M, int C, half_t* y16,
                            int ldy16, float* y32, int ldy32, hipStream_t s) {
-  cast_add_kernel<<<grid1d((size_t)M * C), dim3(256), 0, s>>>(a, lda, b, ldb, bmod, sb, M, C, y16, ldy16, y32, ldy32);
+  const bool vec = (C % 4 == 0) && (lda % 4 == 0) && (!b || ldb % 4 == 0) && (!y16 || ldy16 % 4 == 0) && (!y32 || ldy32 % 4 == 0) &&
+                   ((uintptr_t)a % 16 == 0) && (!b || (uintptr_t)b % 16 == 0) && (!y16 || (uintptr_t)y16 % 8 == 0) &&
+                   (!y32 || (uintptr_t)y32 % 16 == 0);
+  if (vec)
+    cast_add_vec_kernel<<<grid1d((size_t)M * (C / 4)), dim3(256), 0, s>>>(a, lda, b, ldb, bmod, sb, M, C / 4, y16, ldy16, y32, ldy32);
+  else
+    cast_add_kernel<<<grid1d((size_t)M * C), dim3(256), 0, s>>>(a, lda, b, ldb, bmod, sb, M, C, y16, ldy16, y32, ldy32);
   return hipGetLastError();
 }
 hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStream_t s) {

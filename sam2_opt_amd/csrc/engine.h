@@ -106,6 +106,7 @@ struct sam2mi_ctx {
   float* dense_pe = nullptr;         // [4096, 256] token-major
   // ---- memory encoder
   float* md_w[3]; float* md_b[3]; Norm md_ln[4];   // direct convs 1->4, 4->16, 16->64
+  Lin16 md_conv3;                     // [64, 144]  (k = (ky*3+kx)*16 + c)
   Lin16 md_conv4;                     // [256, 576] (k = (ky*3+kx)*64 + c)
   Lin16 md_proj, pix_proj, me_out;    // 1x1 convs
   struct CX { float* dw_w; float* dw_b; Norm ln; Lin16 pw1, pw2; float* gamma; } cx[2];
@@ -147,7 +148,7 @@ struct sam2mi_ctx {
   float* d_low_multi = nullptr; float* d_low_sel = nullptr; float* d_tok_sel = nullptr; int* d_best = nullptr; float* d_iou_sel = nullptr;
   float* d_ptr = nullptr; float* d_pts = nullptr; int* d_labels = nullptr;
   // memory encoder
-  float* m_mask = nullptr; float* m_c1 = nullptr; float* m_c2 = nullptr; half_t* m_c3_16 = nullptr; half_t* m_col16 = nullptr;
+  float* m_mask = nullptr; float* m_c1 = nullptr; float* m_c2 = nullptr; half_t* m_c2_16 = nullptr; half_t* m_c3_16 = nullptr; half_t* m_col16 = nullptr;
   float* m_c4 = nullptr; half_t* m_c4_16 = nullptr; float* m_emb = nullptr; float* m_x = nullptr; float* m_dw = nullptr;
   half_t* m_ln16 = nullptr; half_t* m_h16 = nullptr; float* m_out = nullptr; half_t* m_pix16 = nullptr;
   // plug-boundary scratch (layout conversion)

@@ -526,6 +526,15 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
       ctx->md_b[i] = pk.f32(m + "mask_downsampler.encoder." + std::to_string(3 * i) + ".bias");
     }
     for (int i = 0; i < 4; ++i) ctx->md_ln[i] = pk.norm(m + "mask_downsampler.encoder." + std::to_string(3 * i + 1));
+    if (const HostW* w = pk.get(m + "mask_downsampler.encoder.6.weight")) {
+      const HostW* b = pk.get(m + "mask_downsampler.encoder.6.bias");
+      const int O = (int)w->shape[0], I = (int)w->shape[1];
+      std::vector<float> Wg((size_t)O * 9 * I);
+      for (int o = 0; o < O; ++o)
+        for (int i = 0; i < I; ++i)
+          for (int t = 0; t < 9; ++t) Wg[((size_t)o * 9 + t) * I + i] = w->data[((size_t)o * I + i) * 9 + t];
+      if (b) ctx->md_conv3 = pk.lin16_raw(Wg, b->data, O, 9 * I);
+    }
     if (const HostW* w = pk.get(m + "mask_downsampler.encoder.9.weight")) {
       const HostW* b = pk.get(m + "mask_downsampler.encoder.9.bias");
       const int O = (int)w->shape[0], I = (int)w->shape[1];
@@ -649,6 +658,7 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ALLOC(ctx->m_mask, float, 1024 * 1024);
   ALLOC(ctx->m_c1, float, 512 * 512 * 4);
   ALLOC(ctx->m_c2, float, 256 * 256 * 16);
+  ALLOC(ctx->m_c2_16, half_t, 256 * 256 * 16);
   ALLOC(ctx->m_c3_16, half_t, 128 * 128 * 64);
   ALLOC(ctx->m_col16, half_t, 4096 * 576);
   ALLOC(ctx->m_c4, float, 4096 * 256);

@@ -237,8 +237,15 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* keys_tok, const
 int memenc_forward(sam2mi_ctx* ctx, hipStream_t s, const float* feat2_tok, const float* mask1024, float* out_tok64) {
   // MaskDownSampler: 4 x (conv3x3 s2 + LN2d + GELU), then 1x1
   CHK(conv3x3s2_ln_gelu_launch(mask1024, 1024, 1, 4, ctx->md_w[0], ctx->md_b[0], ctx->md_ln[0].w, ctx->md_ln[0].b, ctx->m_c1, nullptr, s));
-  CHK(conv3x3s2_ln_gelu_launch(ctx->m_c1, 512, 4, 16, ctx->md_w[1], ctx->md_b[1], ctx->md_ln[1].w, ctx->md_ln[1].b, ctx->m_c2, nullptr, s));
-  CHK(conv3x3s2_ln_gelu_launch(ctx->m_c2, 256, 16, 64, ctx->md_w[2], ctx->md_b[2], ctx->md_ln[2].w, ctx->md_ln[2].b, nullptr, ctx->m_c3_16, s));
+  CHK(conv3x3s2_ln_gelu_launch(ctx->m_c1, 512, 4, 16, ctx->md_w[1], ctx->md_b[1], ctx->md_ln[1].w, ctx->md_ln[1].b, nullptr, ctx->m_c2_16, s));
+  // conv 16 -> 64 as im2col + MFMA GEMM (K = 144), then LayerNorm2d + GELU
+  CHK(im2col3x3s2_launch(ctx->m_c2_16, 256, 16, ctx->m_col16, s));
+  {
+    GemmParams p = lin_params(ctx->m_col16, 144, 16384, ctx->md_conv3);
+    p.out32 = ctx->m_c4; p.ld32 = 64;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  CHK(layernorm_launch(ctx->m_c4, 64, ctx->md_ln[2].w, ctx->md_ln[2].b, 1e-6f, 16384, 64, ctx->m_c3_16, 64, nullptr, 0, 1, s));
   CHK(im2col3x3s2_launch(ctx->m_c3_16, 128, 64, ctx->m_col16, s));
   {
     GemmParams p = lin_params(ctx->m_col16, 576, 4096, ctx->md_conv4);

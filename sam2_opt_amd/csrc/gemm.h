@@ -24,6 +24,7 @@ struct GemmParams {
   //   the pair (2p, 2p+1), p = (n % rope_dim) / 2, is rotated by the angle in table row m % rope_len
   const float* rope_cos; const float* rope_sin;  // [rope_len, rope_dim/2]
   int rope_len, rope_rows, rope_cols, rope_dim;
+  int tile_hint;                 // 0 = automatic tile choice; 1..5 force a v2 tile (benchmarks)
 };
 
 static inline GemmParams gemm_params_zero() {
@@ -35,3 +36,6 @@ static inline GemmParams gemm_params_zero() {
 // returns hipSuccess or an error; `flops`/`launches` accumulate statistics when non-null
 hipError_t gemm_launch(const GemmParams& p, hipStream_t stream);
 hipError_t gemm_init();   // sets the dynamic-LDS attributes once
+// gemm2.hip: LDS-DMA pipelined kernel (K % 16 == 0); gemm_launch dispatches to it
+hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t stream);
+hipError_t gemm_v2_init();

@@ -3,6 +3,8 @@
 // the loads of tile k+1 issued before the MFMAs of tile k (one barrier per K-tile); LDS rows
 // are padded by 8 halfs so that the ds_read_b128 fragment reads are bank-conflict free
 // (row strides 80/112/144 B map the 16-lane read groups onto 16 distinct 16-B slots).
+#include <cstdlib>
+
 #include "gemm.h"
 
 template <int BM, int BN, int BK>
@@ -198,7 +200,7 @@ hipError_t gemm_init() {
       gemm_attr<64, 64, 64>(),   gemm_attr<64, 64, 48>(),   gemm_attr<64, 64, 32>()};
   for (int i = 0; i < 9; ++i)
     if (e[i] != hipSuccess) return e[i];
-  return hipSuccess;
+  return gemm_v2_init();
 }
 
 template <int BK>
@@ -213,6 +215,8 @@ static hipError_t gemm_dispatch_tile(const GemmParams& p, hipStream_t s) {
 hipError_t gemm_launch(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if ((p.lda & 7) || (p.ldw & 7) || (p.n_split < p.N && (p.n_split & 31)) || p.K <= 0) return hipErrorInvalidValue;
+  static const bool use_v1 = getenv("SAM2MI_GEMM_V1") != nullptr;      // A/B switch: the register-staged kernel below
+  if (!use_v1 && (p.K & 15) == 0) return gemm_v2_launch(p, s);
   if (p.K % 64 == 0) return gemm_dispatch_tile<64>(p, s);
   if (p.K % 48 == 0) return gemm_dispatch_tile<48>(p, s);
   if (p.K % 32 == 0) return gemm_dispatch_tile<32>(p, s);
