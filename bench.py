@@ -12,7 +12,7 @@ fps = frames / time).  W warm-up steps, then K timed steps between barrier + tor
 time = MAX over ranks; value = N * K * frames / time (weak scaling: independent clips, no data-path collective).
 
 The JSON line also carries
-  roofline     - the dominant kernel (the MFMA GEMM `gemm_f16_kernel`): algorithmic FLOPs / launch time, measured
+  roofline     - the dominant kernel (the MFMA GEMM `gemm_v2_kernel`): algorithmic FLOPs / launch time, measured
                  with HIP events around every GEMM launch on its own stream in a second, un-timed pass of the same
                  K steps (sam2mi_profile_enable), vs the 2.5 PFLOP/s dense f16 MFMA peak;
   cpu_baseline - the CPU oracle (oracle/sam2_ref.py, a port of the reference's torch backend) timed on this
@@ -122,7 +122,7 @@ def main():
         pred.engine.profile_enable(False)
         ach = pr["gemm_flops"] / (pr["gemm_ms"] * 1e-3) / 1e12 if pr["gemm_ms"] > 0 else 0.0
         roofline = {
-            "bound": "mfma", "kernel": "gemm_f16_kernel", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+            "bound": "mfma", "kernel": "gemm_v2_kernel", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
             "launches": int(pr["gemm_launches"]), "gflop_per_launch": round(pr["gemm_flops"] / max(pr["gemm_launches"], 1) / 1e9, 3),
             "avg_launch_us": round(pr["gemm_ms"] * 1e3 / max(pr["gemm_launches"], 1), 2),

@@ -18,7 +18,7 @@ hipError_t hiera_attn_launch(const HieraAttnParams& p, hipStream_t stream);
 
 // ---- single-head d=256 flash attention with split-KV (attn_flash256.hip)
 struct Flash256Params {
-  const half_t* q; int ldq;     // [Nq, ldq] f16 (RoPE already applied), Nq % 128 == 0
+  const half_t* q; int ldq;     // [Nq, ldq] f16, RoPE applied and PRE-SCALED by 256^-0.5 * log2(e); Nq % 128 == 0
   const half_t* k; int ldk;     // [>= ceil32(Nk), ldk] f16
   const half_t* vT; int ldvT;   // V^T [256, ldvT] f16, ldvT >= ceil32(Nk); pad columns must be finite
   int Nq, Nk;
@@ -26,9 +26,10 @@ struct Flash256Params {
   float* o_part;                // [splits, Nq, 256] f32 un-normalised partial outputs
   float* ml_part;               // [splits, Nq, 2] f32 (running max in log2 domain, running sum)
   half_t* out; int ldout;       // [Nq, ldout] f16 final (written by the combine pass)
-  float scale_log2e;
+  float scale_log2e;            // unused by the kernel (q is pre-scaled); kept for the debug entry point
 };
 hipError_t flash256_launch(const Flash256Params& p, hipStream_t stream);
+hipError_t flash256_init();   // dynamic-LDS attribute, once
 
 // ---- tiny fp32 attentions of the two-way mask decoder (attn_small.hip)
 // q [Tq, ldq], k/v [Tk, ld], heads x hd, out [Tq, ldo]; all f32.  softmax(q k^T / sqrt(hd)) v

@@ -19,10 +19,14 @@ constexpr int K_TILE = 32 * KROW;     // halfs
 constexpr int V_TILE = 96 * VROW;     // halfs (rows 72..95 are never written; their products are discarded)
 constexpr int REGION = K_TILE + V_TILE;
 
-template <bool SHARE>
+template <bool SHARE, bool MASK>
 __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p) {
   __shared__ __attribute__((aligned(16))) half_t smem[(SHARE ? 1 : 4) * REGION];
+  constexpr int NTHR = SHARE ? 256 : 64;
+  constexpr int K_IT = (32 * 9 + NTHR - 1) / NTHR;      // 16-B chunks of the K tile per thread
+  constexpr int V_IT = (HD * 8 + NTHR - 1) / NTHR;      // 8-B chunks of the V^T tile per thread
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int st = SHARE ? tid : lane;
   const int fr = lane & 31, fh = lane >> 5;
   const int qtiles = p.GQ / 32;
   const int total = p.num_groups * p.heads * qtiles;
@@ -36,12 +40,9 @@ __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p
   half_t* sK = smem + (SHARE ? 0 : wave * REGION);
   half_t* sV = sK + K_TILE;
   // zero the head-dim pad (cols 72..87) of the K tile once; staging never touches it
-  {
-    const int nthr = SHARE ? 256 : 64, t = SHARE ? tid : lane;
-    for (int i = t; i < 32 * 16; i += nthr) sK[(i >> 4) * KROW + HD + (i & 15)] = (half_t)0.f;
-  }
+  for (int i = st; i < 32 * 16; i += NTHR) sK[(i >> 4) * KROW + HD + (i & 15)] = (half_t)0.f;
 
-  // ---- Q fragments (B operand): lane holds Q[q = fr][d = 16 s + 8 fh + j]
+  // ---- Q fragments (B operand): lane holds Q[q = fr][d = 16 s + 8 fh + j]; Q is pre-scaled by 72^-0.5 * log2(e)
   const size_t qrow = (size_t)grp * p.GQ + qt * 32 + fr;
   half8 qf[5];
 #pragma unroll
@@ -70,27 +71,42 @@ __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p
   const half_t* kbase = p.k + ((size_t)grp * p.GK) * p.ldk + head * HD;
   const half_t* vbase = p.vT + (size_t)head * HD * p.ldvT + (size_t)grp * p.GK;
 
+  // register-staged tiles: the loads of tile t+1 are issued before the MFMAs of tile t
+  half8 rk[K_IT];
+  half4 rv[V_IT];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < K_IT; ++i) {
+      const int c = st + i * NTHR;
+      if (c < 32 * 9) rk[i] = *reinterpret_cast<const half8*>(kbase + (size_t)(k0 + c / 9) * p.ldk + (c % 9) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < V_IT; ++i) {
+      const int c = st + i * NTHR;
+      if (c < HD * 8) rv[i] = *reinterpret_cast<const half4*>(vbase + (size_t)(c >> 3) * p.ldvT + k0 + (c & 7) * 4);
+    }
+  };
+  auto swrite = [&]() {
+#pragma unroll
+    for (int i = 0; i < K_IT; ++i) {
+      const int c = st + i * NTHR;
+      if (c < 32 * 9) *reinterpret_cast<half8*>(sK + (c / 9) * KROW + (c % 9) * 8) = rk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < V_IT; ++i) {
+      const int c = st + i * NTHR;
+      if (c < HD * 8) *reinterpret_cast<half4*>(sV + (c >> 3) * VROW + (c & 7) * 4) = rv[i];
+    }
+  };
+
+  gload(kv_start);
+  swrite();
+  __syncthreads();
+#pragma nounroll
   for (int kt = 0; kt < kv_tiles; ++kt) {
     const int k0 = kv_start + kt * 32;
-    __syncthreads();                                  // previous tile fully consumed
-    {
-      const int nthr = SHARE ? 256 : 64, t = SHARE ? tid : lane;
-      // K tile: 32 rows x 9 chunks of 8 halfs
-      for (int c = t; c < 32 * 9; c += nthr) {
-        const int row = c / 9, ch = c % 9;
-        const half8 v = *reinterpret_cast<const half8*>(kbase + (size_t)(k0 + row) * p.ldk + ch * 8);
-        *reinterpret_cast<half8*>(sK + row * KROW + ch * 8) = v;
-      }
-      // V^T tile: 72 rows x 8 chunks of 4 halfs (8-B LDS writes: rows are 72 B apart)
-      for (int c = t; c < HD * 8; c += nthr) {
-        const int row = c >> 3, ch = c & 7;
-        const half4 v = *reinterpret_cast<const half4*>(vbase + (size_t)row * p.ldvT + k0 + ch * 4);
-        *reinterpret_cast<half4*>(sV + row * VROW + ch * 4) = v;
-      }
-    }
-    __syncthreads();
-
-    // ---- S^T = K Q^T  (32 keys x 32 queries)
+    if (kt + 1 < kv_tiles) gload(k0 + 32);
+    // ---- S^T = K Q^T  (32 keys x 32 queries), exp2 domain
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -99,34 +115,34 @@ __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p
       const half8 kf = *reinterpret_cast<const half8*>(sK + fr * KROW + ks * 16 + fh * 8);
       s = mfma32(kf, qf[ks], s);
     }
-    // ---- online softmax over the key axis (registers + the other lane half)
     float tmax = -1e30f;
-    bool valid[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int kj = k0 + acc_row(r, lane);
-      valid[r] = (kj / p.wk) == q_win;
-      s[r] *= p.scale_log2e;
-      if (valid[r]) tmax = fmaxf(tmax, s[r]);
+      if (MASK && ((k0 + acc_row(r, lane)) / p.wk) != q_win) s[r] = -1e30f;
+      tmax = fmaxf(tmax, s[r]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = exp2f(m_run - m_new);
     float psum = 0.f;
     half8 pf[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float pv = valid[r] ? exp2f(s[r] - m_new) : 0.f;
+      float pv = __builtin_amdgcn_exp2f(s[r] - m_new);
+      if (MASK && s[r] <= -1e30f) pv = 0.f;          // fully masked tile for this query: m_new may still be the sentinel
       psum += pv;
       pf[r >> 3][r & 7] = (half_t)pv;
     }
     psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+    if (__any(m_new > m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      m_run = m_new;
+    }
+    l_run += psum;
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
@@ -139,6 +155,9 @@ __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p
         o[t] = mfma32(vf, pf[ks], o[t]);
       }
     }
+    __syncthreads();                                  // tile fully consumed
+    if (kt + 1 < kv_tiles) swrite();
+    __syncthreads();
   }
 
   if (live) {
@@ -169,9 +188,13 @@ hipError_t hiera_attn_launch(const HieraAttnParams& p, hipStream_t stream) {
   const int qtiles = p.GQ / 32;
   const int total = p.num_groups * p.heads * qtiles;
   const int blocks = (total + 3) / 4;
-  if (qtiles % 4 == 0)
-    hiera_attn_kernel<true><<<dim3(blocks), dim3(256), 0, stream>>>(p);
-  else
-    hiera_attn_kernel<false><<<dim3(blocks), dim3(256), 0, stream>>>(p);
+  const bool mask = !(p.wq >= p.GQ && p.wk >= p.GK);
+  if (qtiles % 4 == 0) {
+    if (mask) hiera_attn_kernel<true, true><<<dim3(blocks), dim3(256), 0, stream>>>(p);
+    else hiera_attn_kernel<true, false><<<dim3(blocks), dim3(256), 0, stream>>>(p);
+  } else {
+    if (mask) hiera_attn_kernel<false, true><<<dim3(blocks), dim3(256), 0, stream>>>(p);
+    else hiera_attn_kernel<false, false><<<dim3(blocks), dim3(256), 0, stream>>>(p);
+  }
   return hipGetLastError();
 }

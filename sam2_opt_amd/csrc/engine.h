@@ -38,6 +38,7 @@ struct HieraBlockW {
   bool q_pool, stage_end;
   Norm n1, n2;
   Lin16 qkv, proj, fc1, fc2, sc;   // sc: dim-change shortcut projection (blocks 2, 8, 44)
+  float* qscale = nullptr;         // [3*dim_out] column scale of the QKV GEMM: q columns *= 72^-0.5*log2(e), k/v columns 1
 };
 
 struct MemAttnLayerW {
@@ -87,6 +88,8 @@ struct sam2mi_ctx {
   Norm ma_norm;
   float* rope_cos = nullptr;         // [4096, 128]
   float* rope_sin = nullptr;
+  float* qs_self = nullptr;          // [768] q columns *= 256^-0.5*log2(e) (softmax runs in the exp2 domain)
+  float* qs_cross = nullptr;         // [256]
   // ---- SAM heads
   std::vector<DecLayerW> dec;
   Lin32 fin_q, fin_o;

@@ -238,6 +238,7 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   if (ctx->cfg.bank_slots <= 0) ctx->cfg.bank_slots = 64;
   if (ctx->cfg.feat_slots <= 0) ctx->cfg.feat_slots = 16;
   hipError_t e = gemm_init();
+  if (e == hipSuccess) e = flash256_init();
   if (e != hipSuccess) {
     sam2mi_set_error(nullptr, "gemm_init", hipGetErrorString(e));
     delete ctx;
@@ -350,6 +351,11 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
       b.fc1 = pk.lin16(p + "mlp.layers.0");
       b.fc2 = pk.lin16(p + "mlp.layers.1");
       if (dim != dim_out) b.sc = pk.lin16(p + "proj");
+      {
+        std::vector<float> qs((size_t)3 * dim_out, 1.0f);
+        for (int k = 0; k < dim_out; ++k) qs[k] = 1.4426950408889634f / std::sqrt(72.0f);
+        b.qscale = dupload(ctx, qs);
+      }
       ctx->blocks.push_back(b);
       dim = dim_out;
     }
@@ -432,6 +438,10 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
     }
     ctx->rope_cos = dupload(ctx, rc);
     ctx->rope_sin = dupload(ctx, rs);
+    std::vector<float> qs(768, 1.0f), qc(256, 1.4426950408889634f / 16.0f);
+    for (int k = 0; k < 256; ++k) qs[k] = 1.4426950408889634f / 16.0f;
+    ctx->qs_self = dupload(ctx, qs);
+    ctx->qs_cross = dupload(ctx, qc);
   }
 
   // ---- SAM heads

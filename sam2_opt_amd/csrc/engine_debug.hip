@@ -55,7 +55,7 @@ extern "C" int sam2mi_debug_hiera_attention(sam2mi_ctx* ctx, void* stream, const
   half_t* vT = t.get<half_t>((size_t)C * Mk);
   half_t* o16 = t.get<half_t>((size_t)Mq * C);
   if (!q16 || !k16 || !vT || !o16) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
-  CHK(cast_add_launch(q, C, nullptr, 0, 0, 0.f, Mq, C, q16, C, nullptr, 0, s));
+  CHK(cast_add_launch(q, C, q, C, 0, 1.4426950408889634f / sqrtf(72.f) - 1.f, Mq, C, q16, C, nullptr, 0, s));   // pre-scaled q
   CHK(cast_add_launch(k, C, nullptr, 0, 0, 0.f, Mk, C, k16, C, nullptr, 0, s));
   transpose_to_f16_kernel<<<dim3((unsigned)(((size_t)Mk * C + 255) / 256)), dim3(256), 0, s>>>(v, vT, Mk, C, Mk);
   CHK(hipGetLastError());
@@ -84,7 +84,7 @@ extern "C" int sam2mi_debug_flash256(sam2mi_ctx* ctx, void* stream, const float*
   float* opart = t.get<float>((size_t)splits * Nq * 256);
   float* ml = t.get<float>((size_t)splits * Nq * 2);
   if (!q16 || !k16 || !vT || !o16 || !opart || !ml) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
-  CHK(cast_add_launch(q, 256, nullptr, 0, 0, 0.f, Nq, 256, q16, 256, nullptr, 0, s));
+  CHK(cast_add_launch(q, 256, q, 256, 0, 1.4426950408889634f / 16.f - 1.f, Nq, 256, q16, 256, nullptr, 0, s));   // pre-scaled q
   CHK(cast_add_launch(k, 256, nullptr, 0, 0, 0.f, Nk, 256, k16, 256, nullptr, 0, s));
   transpose_to_f16_kernel<<<dim3((unsigned)(((size_t)Nk * 256 + 255) / 256)), dim3(256), 0, s>>>(v, vT, Nk, 256, NkP);
   CHK(hipGetLastError());

@@ -41,6 +41,7 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
     {
       GemmParams p = lin_params(ctx->t_h16, C, S, L.self_qkv);
       p.n_split = 512; p.out16 = ctx->t_qk16; p.ld16 = 512; p.outT16 = ctx->t_vT16; p.ldT16 = S;
+      p.col_scale = ctx->qs_self;
       p.rope_cos = ctx->rope_cos; p.rope_sin = ctx->rope_sin; p.rope_len = S; p.rope_rows = S; p.rope_cols = 512; p.rope_dim = C;
       CHKI(run_gemm(ctx, s, p));
     }
@@ -61,7 +62,7 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
     CHK(layernorm_launch(x, C, L.n2.w, L.n2.b, 1e-5f, S, C, ctx->t_h16, C, nullptr, 0, 0, s));
     {
       GemmParams p = lin_params(ctx->t_h16, C, S, L.cross_q);
-      p.out16 = ctx->t_q16; p.ld16 = C;
+      p.out16 = ctx->t_q16; p.ld16 = C; p.col_scale = ctx->qs_cross;
       p.rope_cos = ctx->rope_cos; p.rope_sin = ctx->rope_sin; p.rope_len = S; p.rope_rows = S; p.rope_cols = C; p.rope_dim = C;
       CHKI(run_gemm(ctx, s, p));
     }
