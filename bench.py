@@ -36,6 +36,17 @@ PEAK_F16_TFLOPS = 2500.0                 # dense f16/bf16 MFMA peak of MI355X (M
 CLIP_GFLOP_PROPAGATE = 240450.0          # algorithmic GFLOP of one 100-frame propagate loop
 
 
+def _pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE and
+    WRITE_SIZE runs, gfx950 x2 fetch correction; profiles/r01_b_pmc_traffic.md).  PMC collection cannot run inside the
+    timed process, so this is the last committed measurement, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["gemm_v2_kernel"]["bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,19 +59,15 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the clip timed on the CPU oracle")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from sam2_opt_amd import dist as D
+    rank, local_rank, world = D.rank_world()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = D.init("nccl", device)          # RCCL over xGMI; None when N == 1
 
     from sam2_opt_amd.config import get_config
     from sam2_opt_amd.synthetic import normalize_frames, synthetic_frames_u8
@@ -69,8 +76,8 @@ def main():
 
     cfg = get_config("large")
     sd = synthetic_state_dict(cfg, seed=0)
-    pred = SAM2VideoPredictor("large", state_dict=sd, encode_batch=args.encode_batch, device=torch.device("cuda", local_rank))
-    frames_u8 = synthetic_frames_u8(seed=2 + rank, num_frames=args.frames)
+    pred = SAM2VideoPredictor("large", state_dict=sd, encode_batch=args.encode_batch, device=device)
+    frames_u8 = synthetic_frames_u8(seed=D.clip_seed_for_rank(2, rank), num_frames=args.frames)
     frames = normalize_frames(frames_u8, cfg)
     state = pred.init_state(frames=frames, video_height=1024, video_width=1024)       # frames resident in HBM from here on
     pred.add_new_points_or_box(state, 0, 1, points=np.array([[512.0, 512.0]], np.float32), labels=np.array([1], np.int32))
@@ -83,9 +90,7 @@ def main():
         return n, chk
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        D.barrier(dist, device)
 
     for _ in range(args.warmup):
         one_step()
@@ -99,17 +104,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     checksum = float((last > 0).float().mean().item())
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        # the trivial result gather: (frames, seconds, mask checksum) per rank
-        mine = torch.tensor([nframes, dt, checksum], dtype=torch.float64, device="cuda")
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        total_frames = int(sum(int(x[0].item()) for x in allr))
-    else:
-        total_frames = nframes
+    # MAX over ranks + the trivial result gather (frames, seconds, mask checksum) per rank
+    dt, total_frames, records = D.reduce_time_and_gather(dist, nframes, dt, checksum, device)
     value = total_frames / dt
 
     roofline = None
@@ -123,7 +119,7 @@ def main():
         ach = pr["gemm_flops"] / (pr["gemm_ms"] * 1e-3) / 1e12 if pr["gemm_ms"] > 0 else 0.0
         roofline = {
             "bound": "mfma", "kernel": "gemm_v2_kernel", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": _pmc_traffic(),
             "launches": int(pr["gemm_launches"]), "gflop_per_launch": round(pr["gemm_flops"] / max(pr["gemm_launches"], 1) / 1e9, 3),
             "avg_launch_us": round(pr["gemm_ms"] * 1e3 / max(pr["gemm_launches"], 1), 2),
             "gemm_share_of_timed_region": round(pr["gemm_ms"] * 1e-3 / dt, 3),
@@ -159,7 +155,7 @@ def main():
             "config": {"workload": f"config3: {args.frames}-frame 1024x1024 clip per GPU, 1 click, 1 object, SAM2.1-hiera-large "
                                    "(random-init weights), propagate_in_video loop", "frames_per_step": args.frames,
                        "encode_batch": args.encode_batch, "parallelism": f"clips x{world} (one process per GPU)",
-                       "ms_per_frame": round(dt / max(nframes, 1) * 1e3, 3), "mask_checksum": round(checksum, 6)},
+                       "ms_per_frame": round(dt / max(nframes, 1) * 1e3, 3), "mask_checksum": round(checksum, 6), "per_rank": records},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out), flush=True)

@@ -133,6 +133,13 @@ int sam2mi_video_encode_memory(sam2mi_ctx* ctx, void* stream, int feat_slot, int
 int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, const sam2mi_mem_select* sel, int bank_slot,
                        int run_mem_encoder, const sam2mi_frame_out* out);
 
+/* Image predictor: prompt encoder + mask decoder on a cached frame (SAM2ImagePredictor._predict,
+ * sam2_image_predictor.py:487-589: features + no_mem_embed, no object-score gating).  One prompt of Np points
+ * (labels 0/1 points, 2/3 box corners).  multimask: masks_out (3,256,256) + iou_out (3); otherwise the dynamic
+ * stability fallback picks one: masks_out (1,256,256) + iou_out (1). */
+int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int Np,
+                         int multimask, float* masks_out, float* iou_out);
+
 /* Bilinear resize (align_corners=False) of a (H_in,W_in) fp32 map, F.interpolate semantics
  * (_get_orig_video_res_output, sam2_video_predictor_official.py:489-509). */
 int sam2mi_resize_bilinear(sam2mi_ctx* ctx, void* stream, const float* in, int C, int Hin, int Win, float* out, int Hout, int Wout);

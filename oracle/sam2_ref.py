@@ -601,3 +601,18 @@ class VideoOracle:
             else:
                 low = self.track_frame(t)
             yield t, self._video_res(low)
+
+
+# ----------------------------------------------------------------------------- image predictor (a18)
+def image_predict(feats, points, labels, multimask_output, orig_hw, sd, cfg, return_logits=True, mask_threshold=0.0):
+    """SAM2ImagePredictor._predict (sam2_image_predictor.py:487-589) on `feats` = set_image_e2e output for ONE image.
+    points (B,Np,2) already in 1024-pixel units, labels (B,Np)."""
+    f0, f1, f2 = feats
+    B = points.shape[0]
+    sparse, dense = prompt_encoder(points, labels, sd, cfg, None)
+    low, iou, _, _ = mask_decoder(f2, sparse, dense, f0, f1, multimask_output, B > 1, sd, cfg)
+    masks = F.interpolate(low.float(), orig_hw, mode="bilinear", align_corners=False)
+    low = torch.clamp(low, -32.0, 32.0)
+    if not return_logits:
+        masks = masks > mask_threshold
+    return masks, iou, low

@@ -234,6 +234,30 @@ extern "C" int sam2mi_video_click(sam2mi_ctx* ctx, void* stream, int feat_slot, 
   return sam_heads_finish(ctx, s, multimask, bank_slot, out);
 }
 
+extern "C" int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int Np,
+                                    int multimask, float* masks_out, float* iou_out) {
+  REQUIRE_READY();
+  hipStream_t s = S(stream);
+  if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size()) return sam2mi_set_error(ctx, __func__, "slot out of range");
+  const sam2mi_ctx::FeatSlot& f = ctx->feats[feat_slot];
+  CHK(cast_add_launch(f.feat2, 256, ctx->no_mem_embed, 256, 1, 1.f, 4096, 256, nullptr, 0, ctx->t_pix, 256, s));
+  int T = 0;
+  CHKI(build_tokens(ctx, s, coords, labels, Np, T));
+  CHKI(decoder_forward(ctx, s, ctx->t_pix, ctx->no_mask_embed, 1, ctx->dense_pe, ctx->d_sparse, T, f.fpn0, f.fpn1));
+  if (multimask) {
+    if (masks_out) CHK(hipMemcpyAsync(masks_out, ctx->d_masks + 65536, (size_t)3 * 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (iou_out) CHK(hipMemcpyAsync(iou_out, ctx->d_iou + 1, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  } else {
+    // MaskDecoder._dynamic_multimask_via_stability (mask_decoder.py:346-382); "object present" forced on: no gating here
+    CHK(fill_f32_launch(ctx->d_t1, 1.f, 1, s));
+    CHK(select_mask_launch(ctx->d_masks, ctx->d_iou, ctx->d_t1, ctx->d_mtok, 0, ctx->d_best + 2, 0.05f, 0.98f, nullptr,
+                           ctx->d_low_sel, ctx->d_tok_sel, ctx->d_best, ctx->d_iou_sel, s));
+    if (masks_out) CHK(hipMemcpyAsync(masks_out, ctx->d_low_sel, 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (iou_out) CHK(hipMemcpyAsync(iou_out, ctx->d_iou_sel, sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  return 0;
+}
+
 extern "C" int sam2mi_video_encode_memory(sam2mi_ctx* ctx, void* stream, int feat_slot, int bank_slot, int is_mask_from_pts) {
   REQUIRE_READY();
   hipStream_t s = S(stream);

@@ -1,0 +1,142 @@
+"""SAM2ImagePredictor on the MI355X-native backend - host-side mirror of the reference class
+(/root/reference/sam2/sam2/sam2_image_predictor.py: set_image :140-171, set_image_batch :279-300,
+predict :387-454, _prep_prompts :456-485, _predict :487-589; coordinate transforms utils/transforms.py:50-76,
+postprocess_masks :78-120 with max_hole_area = max_sprinkle_area = 0).
+
+Images enter as uint8 HWC arrays like in the reference.  Inputs that are not 1024x1024 are resized with the same
+operator torchvision's tensor `Resize` uses (bilinear, antialias) through PyTorch - frame ingest is outside the hot
+path; everything after that runs in libsam2mi.so.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .config import get_config
+from .native import Engine
+
+
+class SAM2ImagePredictor:
+    def __init__(self, model: str = "large", state_dict=None, ckpt_path: Optional[str] = None, device=None,
+                 mask_threshold: float = 0.0, max_batch: int = 8):
+        self.cfg = get_config(model)
+        if state_dict is None and ckpt_path is not None:
+            state_dict = torch.load(ckpt_path, map_location="cpu", weights_only=True)["model"]
+        if state_dict is None:
+            raise ValueError("state_dict or ckpt_path is required")
+        self.max_batch = max_batch
+        self.engine = Engine(self.cfg, state_dict=state_dict, max_batch=max_batch, feat_slots=max(2 * max_batch, 16), device=device)
+        self.device = self.engine.device
+        self.mask_threshold = mask_threshold
+        self.image_size = self.cfg["image_size"]
+        self.reset_predictor()
+
+    def speedup(self, backend: str = "hip", use_cache: bool = True, model_root_path=None):
+        if backend not in ("hip", "mi355x", "sam2mi"):
+            raise RuntimeError(f"Unknown backend={backend}: this predictor only runs the MI355X HIP backend")
+
+    def release(self):
+        self.engine.close()
+
+    def reset_predictor(self):
+        self._is_image_set = False
+        self._orig_hw: List = []
+        self._slots: List[int] = []
+
+    # ------------------------------------------------------------------ images
+    @torch.no_grad()
+    def set_image(self, image):
+        if not isinstance(image, np.ndarray):          # PIL image
+            image = np.array(image)
+        self.set_image_batch([image])
+
+    @torch.no_grad()
+    def set_image_batch(self, image_list: List[np.ndarray]):
+        self.reset_predictor()
+        assert isinstance(image_list, list)
+        if len(image_list) > self.engine.feat_slots:
+            raise ValueError(f"at most {self.engine.feat_slots} images per batch (feat_slots)")
+        S = self.image_size
+        mean = torch.tensor(self.cfg["img_mean"], device=self.device).view(1, 3, 1, 1)
+        std = torch.tensor(self.cfg["img_std"], device=self.device).view(1, 3, 1, 1)
+        tensors = []
+        for im in image_list:
+            assert isinstance(im, np.ndarray), "Images are expected to be an np.ndarray in RGB format, and of shape  HWC"
+            self._orig_hw.append(tuple(im.shape[:2]))
+            t = torch.from_numpy(im).to(self.device).permute(2, 0, 1)[None].float() / 255.0
+            if t.shape[-2:] != (S, S):
+                t = F.interpolate(t, size=(S, S), mode="bilinear", align_corners=False, antialias=True)
+            tensors.append((t - mean) / std)
+        self._slots = list(range(len(tensors)))
+        for i in range(0, len(tensors), self.max_batch):
+            batch = torch.cat(tensors[i:i + self.max_batch], dim=0).contiguous()
+            self.engine.video_encode(batch, self._slots[i:i + self.max_batch])
+        self._is_image_set = True
+
+    # ------------------------------------------------------------------ prompts
+    def _coords(self, coords, normalize, orig_hw):
+        c = np.asarray(coords, np.float32).copy()
+        if normalize:
+            h, w = orig_hw
+            c[..., 0] /= w
+            c[..., 1] /= h
+        return c * self.image_size
+
+    @torch.no_grad()
+    def predict(self, point_coords=None, point_labels=None, box=None, mask_input=None, multimask_output=True,
+                return_logits=False, normalize_coords=True, img_idx: int = -1):
+        masks, iou, low = self._predict(point_coords, point_labels, box, mask_input, multimask_output, return_logits,
+                                        normalize_coords, img_idx)
+        return masks[0].float().cpu().numpy(), iou[0].float().cpu().numpy(), low[0].float().cpu().numpy()
+
+    @torch.no_grad()
+    def predict_batch(self, point_coords_batch=None, point_labels_batch=None, box_batch=None, mask_input_batch=None,
+                      multimask_output=True, return_logits=False, normalize_coords=True):
+        """Per image: (masks, ious, low_res) for that image's prompts (B prompts each)."""
+        if not self._is_image_set:
+            raise RuntimeError("An image must be set with .set_image_batch(...) before mask prediction.")
+        outs = []
+        for i in range(len(self._slots)):
+            pc = None if point_coords_batch is None else point_coords_batch[i]
+            pl = None if point_labels_batch is None else point_labels_batch[i]
+            bx = None if box_batch is None else box_batch[i]
+            m, s, l = self._predict(pc, pl, bx, None, multimask_output, return_logits, normalize_coords, i)
+            outs.append((m.float().cpu().numpy(), s.float().cpu().numpy(), l.float().cpu().numpy()))
+        return outs
+
+    def _predict(self, point_coords, point_labels, box, mask_input, multimask_output, return_logits, normalize_coords, img_idx):
+        if not self._is_image_set:
+            raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")
+        if mask_input is not None:
+            raise NotImplementedError("mask prompts are not implemented on this backend yet")
+        orig_hw = self._orig_hw[img_idx]
+        slot = self._slots[img_idx]
+        pts = lab = None
+        if point_coords is not None:
+            assert point_labels is not None, "point_labels must be supplied if point_coords is supplied."
+            pts = self._coords(point_coords, normalize_coords, orig_hw)
+            lab = np.asarray(point_labels, np.int32)
+            if pts.ndim == 2:
+                pts, lab = pts[None], lab[None]
+        if box is not None:
+            b = self._coords(np.asarray(box, np.float32).reshape(-1, 2, 2), normalize_coords, orig_hw)
+            bl = np.tile(np.array([[2, 3]], np.int32), (b.shape[0], 1))
+            pts = b if pts is None else np.concatenate([b, pts], axis=1)
+            lab = bl if lab is None else np.concatenate([bl, lab], axis=1)
+        if pts is None:
+            raise NotImplementedError("prompt-free prediction is not implemented on this backend yet")
+        lows, ious = [], []
+        for b in range(pts.shape[0]):                                  # one decoder pass per prompt (repeat_image)
+            m, s = self.engine.image_predict(slot, pts[b], lab[b], multimask_output)
+            lows.append(m)
+            ious.append(s)
+        low = torch.stack(lows, dim=0)
+        iou = torch.stack(ious, dim=0)
+        masks = self.engine.resize_bilinear(low, orig_hw) if tuple(low.shape[-2:]) != tuple(orig_hw) else low
+        low = torch.clamp(low, -32.0, 32.0)
+        if not return_logits:
+            masks = masks > self.mask_threshold
+        return masks, iou, low

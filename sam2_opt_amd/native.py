@@ -18,7 +18,7 @@ EXPORTS = [
     "sam2mi_abi_version", "sam2mi_create", "sam2mi_destroy", "sam2mi_last_error", "sam2mi_load_weight",
     "sam2mi_finalize_weights", "sam2mi_image_encoder", "sam2mi_set_image_e2e", "sam2mi_memory_attention",
     "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_dense_pe", "sam2mi_video_encode",
-    "sam2mi_video_click", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_resize_bilinear",
+    "sam2mi_video_click", "sam2mi_image_predict", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_resize_bilinear",
     "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
     "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench",
 ]
@@ -228,6 +228,16 @@ class Engine:
         self._check(self.lib.sam2mi_video_click(self.h, self.stream, feat_slot, coords.ctypes.data_as(C.c_void_p),
                                                 labels.ctypes.data_as(C.c_void_p), len(labels), int(multimask), bank_slot,
                                                 C.byref(fo)), "sam2mi_video_click")
+
+    def image_predict(self, feat_slot: int, coords: np.ndarray, labels: np.ndarray, multimask: bool):
+        coords = np.ascontiguousarray(coords, np.float32).reshape(-1, 2)
+        labels = np.ascontiguousarray(labels, np.int32).reshape(-1)
+        c = 3 if multimask else 1
+        masks, iou = self.new(c, 256, 256), self.new(c)
+        self._check(self.lib.sam2mi_image_predict(self.h, self.stream, feat_slot, coords.ctypes.data_as(C.c_void_p),
+                                                  labels.ctypes.data_as(C.c_void_p), len(labels), int(multimask), _ptr(masks), _ptr(iou)),
+                    "sam2mi_image_predict")
+        return masks, iou
 
     def video_encode_memory(self, feat_slot: int, bank_slot: int, is_mask_from_pts: bool):
         self._check(self.lib.sam2mi_video_encode_memory(self.h, self.stream, feat_slot, bank_slot, int(is_mask_from_pts)),
