@@ -64,37 +64,41 @@ def speedup_hip(predictor, plugs=("image", "memory_attention", "mask_decoder", "
     if "image" in plugs:
         ex = HipExecutor(eng, eng.image_encoder, 1)
         model.backend_contexts = [ex]
-        model.inference_image = lambda img: tuple(ex.Inference([img]))
+        model.inference_image = lambda img, _ex=ex: tuple(_ex.Inference([img]))
         if hasattr(predictor, "set_image_e2e"):            # SAM2ImagePredictor
             ex2 = HipExecutor(eng, eng.set_image_e2e, 1)
             predictor.backend_contexts = [ex2]
-            predictor.set_image_e2e = lambda img: tuple(ex2.Inference([img]))
+            predictor.set_image_e2e = lambda img, _ex=ex2: tuple(_ex.Inference([img]))
     ma = getattr(model, "memory_attention", None)
     if ma is not None and "memory_attention" in plugs:
         ex = HipExecutor(eng, eng.memory_attention, 6)
         ma.backend_contexts = [ex, ex]
-        fn = lambda *a: ex.Inference(list(a))[0]           # noqa: E731
+        fn = lambda *a, _ex=ex: _ex.Inference(list(a))[0]           # noqa: E731
         ma.inference_memory_attention_exclude = fn
         ma.inference_memory_attention_none = fn
     md = getattr(model, "sam_mask_decoder", None)
     if md is not None and "mask_decoder" in plugs:
         ex = HipExecutor(eng, eng.mask_decoder, 5)
         md.backend_contexts = [ex]
-        md.inference_predict_masks = lambda *a: tuple(ex.Inference(list(a)))
+        md.inference_predict_masks = lambda *a, _ex=ex: tuple(_ex.Inference(list(a)))
     me = getattr(model, "memory_encoder", None)
     if me is not None and "memory_encoder" in plugs:
         ex = HipExecutor(eng, eng.memory_encoder, 2)
         me.backend_contexts = [ex]
-        me.inference_memory = lambda pix, m: tuple(ex.Inference([pix, m]))
+        me.inference_memory = lambda pix, m, _ex=ex: tuple(_ex.Inference([pix, m]))
     return predictor
 
 
 def release_hip(predictor):
     """Back to the PyTorch methods (what `predictor.speedup("torch")` / `release()` do) and free the engine."""
     model = getattr(predictor, "model", predictor)
+    seen = set()
     for mod in (predictor, model, getattr(model, "memory_attention", None), getattr(model, "sam_mask_decoder", None),
                 getattr(model, "memory_encoder", None)):
-        if mod is not None and hasattr(mod, "set_runtime_backend"):
+        if mod is None or id(mod) in seen:
+            continue
+        seen.add(id(mod))
+        if hasattr(mod, "set_runtime_backend"):
             mod.backend_contexts = []
             mod.set_runtime_backend("torch")
     eng = getattr(model, "_sam2mi_engine", None)

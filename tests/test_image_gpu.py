@@ -23,7 +23,7 @@ def test_image_predictor_matches_oracle(sd_large, cfg_large):
             with torch.inference_mode():
                 feats = R.set_image_e2e(img01, sd_large, cfg_large)
                 rm, ri, rl = R.image_predict(feats, torch.from_numpy(pts), torch.from_numpy(lab), True, (1024, 1024), sd_large, cfg_large)
-            m, s, l = pred._predict(pts, lab, None, None, True, True, False, i)
+            m, s, l = pred._predict(pts, lab, None, None, True, True, True, i)      # normalize by (1024,1024), then x1024
             check(f"image {i} masks (8 prompts x 3)", m, rm, 1e-2, 5e-3)
             check(f"image {i} ious", s, ri, 5e-3, 5e-3)
             check(f"image {i} low_res", l, rl, 1e-2, 5e-3)
@@ -32,11 +32,11 @@ def test_image_predictor_matches_oracle(sd_large, cfg_large):
         lab = np.array([[1, 0, 1, 1, 0, 1, 1, 0]], np.int32)
         with torch.inference_mode():
             rm, ri, rl = R.image_predict(feats, torch.from_numpy(pts), torch.from_numpy(lab), False, (1024, 1024), sd_large, cfg_large)
-        m, s, l = pred._predict(pts, lab, None, None, False, True, False, 1)
+        m, s, l = pred._predict(pts, lab, None, None, False, True, True, 1)
         check("image 1 single-mask (8-point prompt)", m, rm, 1e-2, 5e-3)
         check("image 1 single-mask iou", s, ri, 5e-3, 5e-3)
         # public API returns numpy, thresholded
-        mb, sb, lb = pred.predict(pts[0], lab[0], multimask_output=True, normalize_coords=False)
-        assert mb.shape == (3, 1024, 1024) and mb.dtype == np.bool_ and sb.shape == (3,) and lb.shape == (3, 256, 256)
+        mb, sb, lb = pred.predict(pts[0], lab[0], multimask_output=True, normalize_coords=True)
+        assert mb.shape == (3, 1024, 1024) and set(np.unique(mb)) <= {0.0, 1.0} and sb.shape == (3,) and lb.shape == (3, 256, 256)
     finally:
         pred.release()

@@ -45,7 +45,7 @@ def test_image_encoder(eng, oracle_enc):
     got = eng.image_encoder(img.cuda())
     names = ["vision_features", "vision_pos_enc0", "vision_pos_enc1", "vision_pos_enc2", "backbone_fpn0", "backbone_fpn1", "backbone_fpn2"]
     for n, g, r in zip(names, got, outs):
-        tol = (1e-5, 1e-6) if "pos_enc" in n else (2e-2, 1e-2)
+        tol = (1e-5, 1e-6) if "pos_enc" in n else (5e-3, 3e-3)
         check("encoder/" + n, g, r, *tol)
 
 
@@ -54,8 +54,8 @@ def test_image_encoder_batch2_matches_batch1(eng, oracle_enc):
     from sam2_opt_amd.synthetic import synthetic_image_normed
     img2 = torch.cat([synthetic_image_normed(seed=7), img], dim=0).cuda()
     got = eng.image_encoder(img2)
-    check("encoder batch2[1] vision_features", got[0][1:2], outs[0], 2e-2, 1e-2)
-    check("encoder batch2[1] fpn0", got[4][1:2], outs[4], 2e-2, 1e-2)
+    check("encoder batch2[1] vision_features", got[0][1:2], outs[0], 5e-3, 3e-3)
+    check("encoder batch2[1] fpn0", got[4][1:2], outs[4], 5e-3, 3e-3)
 
 
 def test_set_image_e2e(eng, sd_large, cfg_large):
@@ -66,7 +66,7 @@ def test_set_image_e2e(eng, sd_large, cfg_large):
         ref = R.set_image_e2e(img01, sd_large, cfg_large)
     got = eng.set_image_e2e(img01.cuda())
     for n, g, r in zip(("feat0", "feat1", "feat2"), got, ref):
-        check("set_image_e2e/" + n, g, r, 2e-2, 1e-2)
+        check("set_image_e2e/" + n, g, r, 5e-3, 3e-3)
 
 
 @pytest.mark.parametrize("tag", ["memattn_L1P4", "memattn_L3P12", "memattn_L1P0"])
@@ -103,7 +103,7 @@ def test_mask_decoder(eng, sd_large, cfg_large, tag):
     fails = []
     for n, g, r in zip(("masks", "iou", "tokens", "obj"), got, ref):
         try:
-            check(f"{tag}/{n}", g, r, 1e-2, 5e-3)
+            check(f"{tag}/{n}", g, r, 5e-3, 2e-3)
         except AssertionError as e:
             fails.append(str(e))
     assert not fails, fails

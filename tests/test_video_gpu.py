@@ -2,8 +2,8 @@
  (a) golden vectors recorded from the REAL reference's propagate_in_video (tests/golden/large_video24.npz), and
  (b) the CPU oracle's per-frame intermediates on the first frames.
 Tolerances (f16 MFMA operands, f32 accumulate; the memory bank is bf16-rounded as in the reference):
-mask logits max-abs error <= 2e-2 * max|ref| and relative L2 <= 1e-2 per frame, binarised-pixel
-disagreement <= 5e-3."""
+mask logits max-abs error <= 5e-3 * max|ref| and relative L2 <= 5e-3 per frame, binarised-pixel
+disagreement <= 2e-3 (measured: 1.9e-3 / 2.0e-3 / 1.0e-3)."""
 import numpy as np
 import pytest
 import torch
@@ -49,7 +49,7 @@ def test_video_matches_reference_golden(predictor, cfg_large, golden_video):
         n += 1
     assert n == T
     print(f"[parity] video worst over {T} frames: {worst}", flush=True)
-    assert worst["max_rel"] <= 2e-2 and worst["l2"] <= 1e-2 and worst["dis"] <= 5e-3, worst
+    assert worst["max_rel"] <= 5e-3 and worst["l2"] <= 5e-3 and worst["dis"] <= 2e-3, worst
 
 
 def test_video_intermediates_match_oracle(predictor, sd_large, cfg_large):
@@ -67,14 +67,14 @@ def test_video_intermediates_match_oracle(predictor, sd_large, cfg_large):
         st = predictor.init_state(frames=frames, video_height=1024, video_width=1024)
         predictor.add_new_points_or_box(st, 0, 1, points=np.array([CLICK], np.float32), labels=np.array([1], np.int32))
         for t, ids, vm in predictor.propagate_in_video(st, max_frame_num_to_track=NF - 1):
-            check(f"video f{t} mask", vm, ref_masks[t], 2e-2, 1e-2)
+            check(f"video f{t} mask", vm, ref_masks[t], 5e-3, 5e-3)
             if t == 0:
                 continue
             tr, dbg = vo.trace[("track", t)], predictor.debug_trace[(0, t)]
             assert dbg["L"] == tr["memattn_in"][1].shape[0] and dbg["P"] == tr["memattn_in"][4].shape[0]
-            check(f"video f{t} pix_feat", dbg["pix_feat"], tr["pix_feat"].flatten(2).permute(2, 0, 1), 2e-2, 5e-3)
-            check(f"video f{t} ious", dbg["ious"], tr["ious"], 1e-2, 1e-2)
-            check(f"video f{t} obj_ptr", dbg["obj_ptr"], tr["obj_ptr"], 2e-2, 1e-2)
+            check(f"video f{t} pix_feat", dbg["pix_feat"], tr["pix_feat"].flatten(2).permute(2, 0, 1), 1e-2, 5e-3)
+            check(f"video f{t} ious", dbg["ious"], tr["ious"], 5e-3, 5e-3)
+            check(f"video f{t} obj_ptr", dbg["obj_ptr"], tr["obj_ptr"], 1e-2, 5e-3)
             assert int(dbg["best_idx"].item()) == int(torch.argmax(tr["ious"], dim=-1).item())
     finally:
         predictor.debug_trace = None
