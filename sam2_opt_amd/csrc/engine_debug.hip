@@ -36,7 +36,8 @@ extern "C" int sam2mi_debug_gemm(sam2mi_ctx* ctx, void* stream, const float* A, 
   CHK(cast_add_launch(A, K, nullptr, 0, 0, 0.f, M, K, a16, K, nullptr, 0, s));
   CHK(cast_add_launch(W, K, nullptr, 0, 0, 0.f, N, K, w16, K, nullptr, 0, s));
   GemmParams p = gemm_params_zero();
-  p.A = a16; p.lda = K; p.W = w16; p.ldw = K; p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act; p.n_split = N;
+  p.A = a16; p.lda = K; p.W = w16; p.ldw = K; p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act & 0xFF; p.n_split = N;
+  p.tile_hint = act >> 8;            // tests: force a tile / kernel variant
   p.res = residual; p.ldres = N; p.out32 = out; p.ld32 = N;
   CHKI(run_gemm(ctx, s, p));
   CHK(hipStreamSynchronize(s));

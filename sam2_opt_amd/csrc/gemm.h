@@ -39,3 +39,6 @@ hipError_t gemm_init();   // sets the dynamic-LDS attributes once
 // gemm2.hip: LDS-DMA pipelined kernel (K % 16 == 0); gemm_launch dispatches to it
 hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t stream);
 hipError_t gemm_v2_init();
+// gemm3.hip: persistent loader/consumer kernel (large M*N, K % 16 == 0)
+hipError_t gemm_v3_launch(const GemmParams& p, hipStream_t stream);
+hipError_t gemm_v3_init();

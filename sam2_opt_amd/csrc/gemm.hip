@@ -200,7 +200,8 @@ hipError_t gemm_init() {
       gemm_attr<64, 64, 64>(),   gemm_attr<64, 64, 48>(),   gemm_attr<64, 64, 32>()};
   for (int i = 0; i < 9; ++i)
     if (e[i] != hipSuccess) return e[i];
-  return gemm_v2_init();
+  hipError_t e2 = gemm_v2_init();
+  return e2 != hipSuccess ? e2 : gemm_v3_init();
 }
 
 template <int BK>

@@ -24,8 +24,8 @@ namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_v2_kernel(const GemmParams p) {
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM * WN * 64, (STAGES > 2 && WM * WN == 8) ? 2 : 2) void gemm_v2_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -53,71 +53,106 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_v2_kernel(const GemmPara
   const int nk = (p.K + 63) / 64;
   const int srow = lane >> 3, spc = lane & 7;        // row-in-piece and physical 16-B slot of this lane
 
-  // per-lane source offsets of every LDS-DMA piece (row clamp + swizzled chunk), hoisted out of the K loop
-  const half_t* a_src[A_CALLS];
-  const half_t* b_src[B_CALLS];
-  int a_kc[A_CALLS], b_kc[B_CALLS];
+  // LDS-DMA sources: wave-uniform base (tile origin + K offset, scalar registers) + a per-lane 32-bit byte offset per
+  // piece (clamped row + swizzled chunk) computed once -> no vector address arithmetic inside the K loop.
+  // K tail (K % 64 != 0, K >= 64): the last tile is loaded from columns [K-64, K) - always in bounds - and only its
+  // last (K % 64) / 16 k-steps are consumed.  K < 64 (one partial tile): chunks past K are redirected to column 0.
+  const char* baseA = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
+  const char* baseB = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw);
+  unsigned a_off[A_CALLS], b_off[B_CALLS];
+  const bool short_k = p.K < 64;
 #pragma unroll
   for (int j = 0; j < A_CALLS; ++j) {
     const int row = (wave * A_CALLS + j) * 8 + srow;
-    a_kc[j] = (spc ^ ((row >> 1) & 7)) << 3;
-    a_src[j] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + a_kc[j];
+    int kc = (spc ^ ((row >> 1) & 7)) << 3;
+    if (short_k && kc >= p.K) kc = 0;
+    a_off[j] = (unsigned)((min(m0 + row, p.M - 1) - m0) * p.lda + kc) * 2u;
   }
 #pragma unroll
   for (int j = 0; j < B_CALLS; ++j) {
     const int row = (wave * B_CALLS + j) * 8 + srow;
-    b_kc[j] = (spc ^ ((row >> 1) & 7)) << 3;
-    b_src[j] = p.W + (size_t)min(n0 + row, p.N - 1) * p.ldw + b_kc[j];
+    int kc = (spc ^ ((row >> 1) & 7)) << 3;
+    if (short_k && kc >= p.K) kc = 0;
+    b_off[j] = (unsigned)((min(n0 + row, p.N - 1) - n0) * p.ldw + kc) * 2u;
   }
-  const bool k_tail = (p.K & 63) != 0;
+  const int k_tail = short_k ? 0 : (p.K & 63);
   auto issue = [&](int stage, int kt) {
     char* sbase = smem + stage * STAGE;
-    const bool last = k_tail && kt == nk - 1;
+    const int kcol = (k_tail && kt == nk - 1) ? p.K - 64 : kt * 64;       // scalar
+    const char* ka = baseA + (size_t)kcol * 2;
+    const char* kb = baseB + (size_t)kcol * 2;
 #pragma unroll
-    for (int j = 0; j < A_CALLS; ++j) {
-      const half_t* g = a_src[j] + kt * 64;
-      if (last && kt * 64 + a_kc[j] >= p.K) g -= a_kc[j] + kt * 64;      // K tail: slot never consumed, read col 0 instead
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(sbase + (wave * A_CALLS + j) * 1024), 16, 0, 0);
-    }
+    for (int j = 0; j < A_CALLS; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ka + a_off[j]), (lds_ptr_t)(sbase + (wave * A_CALLS + j) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < B_CALLS; ++j) {
-      const half_t* g = b_src[j] + kt * 64;
-      if (last && kt * 64 + b_kc[j] >= p.K) g -= b_kc[j] + kt * 64;
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(sbase + A_BYTES + (wave * B_CALLS + j) * 1024), 16, 0, 0);
-    }
+    for (int j = 0; j < B_CALLS; ++j)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + b_off[j]), (lds_ptr_t)(sbase + A_BYTES + (wave * B_CALLS + j) * 1024), 16, 0, 0);
   };
 
-  issue(0, 0);
-  __syncthreads();
-#pragma nounroll
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) issue(cur ^ 1, kt + 1);
-    const char* sA = smem + cur * STAGE;
-    const char* sB = sA + A_BYTES;
-    const int ksteps = (kt == nk - 1 && (p.K & 63)) ? ((p.K & 63) >> 4) : 4;
-#pragma unroll KUNROLL
-    for (int s = 0; s < ksteps; ++s) {
-      {
-        half8 af[TM], bf[TN];
+  // ---- K pipeline: STAGES-1 tiles in flight, counted vmcnt + raw barrier (a __syncthreads() would drain the DMA queue)
+  constexpr int NPW = A_CALLS + B_CALLS;           // LDS-DMA pieces this wave issues per K tile
+  struct Frag { half8 a[TM]; half8 b[TN]; };
+  auto ldfrag = [&](const char* sA, const char* sB, int s) {
+    Frag f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int row = wm * WTM + i * 32 + fr;
-          af[i] = *reinterpret_cast<const half8*>(sA + row * 128 + (((2 * s + fh) ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int row = wn * WTN + j * 32 + fr;
-          bf[j] = *reinterpret_cast<const half8*>(sB + row * 128 + (((2 * s + fh) ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
-      }
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * WTM + i * 32 + fr;
+      f.a[i] = *reinterpret_cast<const half8*>(sA + row * 128 + (((2 * s + fh) ^ ((row >> 1) & 7)) << 4));
     }
-    __syncthreads();          // retires the in-flight tile (vmcnt(0)) and frees `cur` for the next issue
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * WTN + j * 32 + fr;
+      f.b[j] = *reinterpret_cast<const half8*>(sB + row * 128 + (((2 * s + fh) ^ ((row >> 1) & 7)) << 4));
+    }
+    return f;
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(f.a[i], f.b[j], acc[i][j]);
+  };
+  auto sync_tile = [&](int kt) {                   // tile kt landed & visible; slot of tile kt-1 free; keep the ring full
+    const int later = min(STAGES - 2, nk - 1 - kt);
+    if (STAGES >= 4 && later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+    else if (STAGES >= 3 && later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + STAGES - 1 < nk) issue((kt + STAGES - 1) % STAGES, kt + STAGES - 1);
+  };
+#pragma unroll
+  for (int st = 0; st < STAGES - 1; ++st)
+    if (st < nk) issue(st, st);
+  // full 64-deep tiles: ONE straight-line MFMA path in the loop (a conditional k-step makes the compiler copy all
+  // accumulators at the loop back-edge), fragments of k-step s+1 are read from LDS while the MFMAs of step s run
+  const int nfull = (k_tail || short_k) ? nk - 1 : nk;
+#pragma nounroll
+  for (int kt = 0; kt < nfull; ++kt) {
+    sync_tile(kt);
+    const char* sA = smem + (kt % STAGES) * STAGE;
+    const char* sB = sA + A_BYTES;
+    Frag f0 = ldfrag(sA, sB, 0);
+    Frag f1 = ldfrag(sA, sB, 1);
+    mma(f0);
+    f0 = ldfrag(sA, sB, 2);
+    mma(f1);
+    f1 = ldfrag(sA, sB, 3);
+    mma(f0);
+    mma(f1);
   }
+  if (nfull < nk) {                                // K tail, executed once
+    const int kt = nk - 1;
+    sync_tile(kt);
+    const char* sA = smem + (kt % STAGES) * STAGE;
+    const char* sB = sA + A_BYTES;
+    // K < 64: the first K/16 steps; otherwise the tile holds columns [K-64, K): its last (K % 64)/16 steps
+    const int s_lo = short_k ? 0 : 4 - (k_tail >> 4), s_hi = short_k ? (p.K >> 4) : 4;
+    for (int s = s_lo; s < s_hi; ++s) {
+      const Frag f = ldfrag(sA, sB, s);
+      mma(f);
+    }
+  }
+  __syncthreads();              // every wave is done with the ring before the epilogue patches overwrite it
 
   // ------------------------------------------------------------------ epilogue
   float* patch = reinterpret_cast<float*>(smem) + wave * 1024;     // wave-private 32x32 f32
@@ -234,26 +269,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_v2_kernel(const GemmPara
   }
 }
 
-template <int BM, int BN>
-constexpr size_t v2_smem() { return (size_t)2 * (BM + BN) * 128; }
+template <int BM, int BN, int STAGES>
+constexpr size_t v2_smem() { return (size_t)STAGES * (BM + BN) * 128; }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int STAGES>
 hipError_t v2_launch(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  const size_t smem = v2_smem<BM, BN>();
-  gemm_v2_kernel<BM, BN, WM, WN><<<dim3(tiles), dim3(WM * WN * 64), smem, s>>>(p);
+  const size_t smem = v2_smem<BM, BN, STAGES>();
+  gemm_v2_kernel<BM, BN, WM, WN, STAGES><<<dim3(tiles), dim3(WM * WN * 64), smem, s>>>(p);
   return hipGetLastError();
 }
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int STAGES>
 hipError_t v2_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v2_kernel<BM, BN, WM, WN>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_smem<BM, BN>());
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v2_kernel<BM, BN, WM, WN, STAGES>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_smem<BM, BN, STAGES>());
 }
 }  // namespace
 
 hipError_t gemm_v2_init() {
-  hipError_t e[4] = {v2_attr<256, 128, 4, 2>(), v2_attr<128, 128, 2, 2>(), v2_attr<128, 64, 2, 2>(), v2_attr<64, 64, 2, 2>()};
-  for (int i = 0; i < 4; ++i)
+  hipError_t e[7] = {v2_attr<256, 128, 4, 2, 3>(), v2_attr<128, 128, 2, 2, 2>(), v2_attr<128, 64, 2, 2, 2>(), v2_attr<64, 64, 2, 2, 2>(),
+                     v2_attr<128, 64, 2, 2, 3>(), v2_attr<128, 128, 2, 2, 3>(), v2_attr<64, 64, 2, 2, 4>()};
+  for (int i = 0; i < 7; ++i)
     if (e[i] != hipSuccess) return e[i];
   return hipSuccess;
 }
@@ -265,8 +301,12 @@ static inline long tiles_of(const GemmParams& p, int bm, int bn) { return (long)
 // occupancy (3+ workgroups per CU hiding each other's prologue/epilogue) beat the 256x128 / 128x128 tiles here.
 hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   const int force = p.tile_hint;
-  if (force == 2) return v2_launch<256, 128, 4, 2>(p, s);
-  if (force == 3) return v2_launch<128, 128, 2, 2>(p, s);
-  if (force == 4 || (force == 0 && tiles_of(p, 128, 64) >= 2048)) return v2_launch<128, 64, 2, 2>(p, s);
-  return v2_launch<64, 64, 2, 2>(p, s);
+  if (force == 6) return gemm_v3_launch(p, s);
+  if (force == 2) return v2_launch<256, 128, 4, 2, 3>(p, s);
+  if (force == 3) return v2_launch<128, 128, 2, 2, 2>(p, s);
+  if (force == 7) return v2_launch<128, 64, 2, 2, 3>(p, s);
+  if (force == 8) return v2_launch<128, 128, 2, 2, 3>(p, s);
+  if (force == 9) return v2_launch<64, 64, 2, 2, 4>(p, s);
+  if (force == 4 || (force == 0 && tiles_of(p, 128, 64) >= 2048)) return v2_launch<128, 64, 2, 2, 2>(p, s);
+  return v2_launch<64, 64, 2, 2, 2>(p, s);
 }

@@ -259,7 +259,8 @@ class Engine:
                     attn_flops=v[4].value, attn_launches=v[5].value)
 
     # ------------------------------------------------------------------ single-kernel debug entry points (tests)
-    def debug_gemm(self, A, W, bias=None, act=0, residual=None):
+    def debug_gemm(self, A, W, bias=None, act=0, residual=None, tile_hint=0):
+        act = act | (tile_hint << 8)
         M, K = A.shape
         N = W.shape[0]
         out = self.new(M, N)

@@ -27,13 +27,14 @@ def r16(x):
     (300, 200, 144, 0, False), (4096, 1728, 576, 0, False), (16384, 432, 144, 1, True), (8, 256, 256, 2, False),
     (1000, 64, 160, 0, True), (4096, 4, 32, 0, False), (129, 65, 2304, 1, True), (4096, 576, 2304, 0, True),
 ])
-def test_gemm(eng, M, N, K, act, res):
+@pytest.mark.parametrize("hint", [0, 2, 3, 6])      # automatic tile, 256x128, 128x128, persistent loader/consumer kernel
+def test_gemm(eng, M, N, K, act, res, hint):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
     A = r16(torch.randn(M, K, generator=g)).cuda()
     W = r16(torch.randn(N, K, generator=g) / math.sqrt(K)).cuda()
     b = torch.randn(N, generator=g).cuda()
     R = torch.randn(M, N, generator=g).cuda() if res else None
-    out = eng.debug_gemm(A, W, b, act, R)
+    out = eng.debug_gemm(A, W, b, act, R, tile_hint=hint)
     ref = A.double() @ W.double().t() + b.double()
     if act == 1:
         ref = F.gelu(ref)
@@ -41,7 +42,7 @@ def test_gemm(eng, M, N, K, act, res):
         ref = F.relu(ref)
     if res:
         ref = ref + R.double()
-    check(f"gemm {M}x{N}x{K} act{act}", out, ref.float(), 1e-4, 1e-5)
+    check(f"gemm {M}x{N}x{K} act{act} hint{hint}", out, ref.float(), 1e-4, 1e-5)
 
 
 def _ref_attn(q, k, v, groups, heads, GQ, GK, wq, wk):
