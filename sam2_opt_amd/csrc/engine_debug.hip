@@ -1,5 +1,6 @@
 // Single-kernel entry points behind the C ABI, used by the GPU parity tests (tests/test_kernels_gpu.py).
 #include "engine.h"
+#include <cstdlib>
 
 namespace {
 struct Tmp {
@@ -160,8 +161,10 @@ extern "C" int sam2mi_debug_gemm_bench(sam2mi_ctx* ctx, void* stream, int M, int
   CHK(cast_add_launch(tmp, K, nullptr, 0, 0, 0.f, N, K, w16, K, nullptr, 0, s));
   GemmParams p = gemm_params_zero();
   p.A = a16; p.lda = K; p.W = w16; p.ldw = K; p.M = M; p.N = N; p.K = K; p.n_split = N; p.tile_hint = tile_hint;
+  if (getenv("SAM2MI_BENCH_NOMEM")) { p.lda = 0; p.ldw = 0; }   // tuning aid: every tile reads the same rows (cache-resident operands)
   if (mode == 0) { p.out16 = o16; p.ld16 = N; }            // f16 output (QKV / fc1 style)
-  else { p.out32 = o32; p.ld32 = N; p.res = o32; p.ldres = N; }   // f32 in-place residual (proj / fc2 style)
+  else if (mode == 1) { p.out32 = o32; p.ld32 = N; p.res = o32; p.ldres = N; }   // f32 in-place residual (proj / fc2 style)
+  // mode 2: no output at all (main-loop-only timing, tuning aid)
   for (int i = 0; i < 3; ++i) CHK(gemm_launch(p, s));
   hipEvent_t e0, e1;
   CHK(hipEventCreate(&e0));

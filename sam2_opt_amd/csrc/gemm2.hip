@@ -287,18 +287,21 @@ hipError_t v2_attr() {
 }  // namespace
 
 hipError_t gemm_v2_init() {
-  hipError_t e[7] = {v2_attr<256, 128, 4, 2, 3>(), v2_attr<128, 128, 2, 2, 2>(), v2_attr<128, 64, 2, 2, 2>(), v2_attr<64, 64, 2, 2, 2>(),
-                     v2_attr<128, 64, 2, 2, 3>(), v2_attr<128, 128, 2, 2, 3>(), v2_attr<64, 64, 2, 2, 4>()};
-  for (int i = 0; i < 7; ++i)
+  hipError_t e[11] = {v2_attr<256, 128, 4, 2, 3>(), v2_attr<128, 128, 2, 2, 2>(), v2_attr<128, 64, 2, 2, 2>(), v2_attr<64, 64, 2, 2, 2>(),
+                      v2_attr<128, 64, 2, 2, 3>(), v2_attr<128, 128, 2, 2, 3>(), v2_attr<64, 64, 2, 2, 4>(),
+                      v2_attr<128, 128, 4, 2, 2>(), v2_attr<256, 128, 4, 2, 2>(), v2_attr<256, 64, 4, 2, 2>(), v2_attr<128, 64, 4, 2, 2>()};
+  for (int i = 0; i < 11; ++i)
     if (e[i] != hipSuccess) return e[i];
   return hipSuccess;
 }
 
 static inline long tiles_of(const GemmParams& p, int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); }
 
-// Tile choice (measured on MI355X, tools/gemm_bench.py): with K <= 4608 every output tile is a short K loop whose
-// prologue (first LDS-DMA round trip) and epilogue are not overlapped inside a workgroup, so small tiles at high
-// occupancy (3+ workgroups per CU hiding each other's prologue/epilogue) beat the 256x128 / 128x128 tiles here.
+// Tile choice (measured on MI355X, tools/gemm_bench.py; DESIGN.md "GEMM tuning log").  This is a one-barrier-per-K-tile
+// structure at 2-3 workgroups per CU: its main loop tops out near 900 TFLOP/s even on cache-resident operands, and with
+// K <= 4608 the un-overlapped prologue / epilogue of every output tile costs another 20-25 %.  What helps is waves:
+// 8-wave workgroups beat 4-wave ones on every large shape; 128x128 (2 per CU) wins when N pads to 128 with <= 8 % waste,
+// 128x64 (3 per CU) otherwise; 256x128 and 3/4-stage rings (1 workgroup per CU) lose 30-50 %.
 hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   const int force = p.tile_hint;
   if (force == 6) return gemm_v3_launch(p, s);
@@ -307,6 +310,16 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   if (force == 7) return v2_launch<128, 64, 2, 2, 3>(p, s);
   if (force == 8) return v2_launch<128, 128, 2, 2, 3>(p, s);
   if (force == 9) return v2_launch<64, 64, 2, 2, 4>(p, s);
-  if (force == 4 || (force == 0 && tiles_of(p, 128, 64) >= 2048)) return v2_launch<128, 64, 2, 2, 2>(p, s);
+  if (force == 10) return v2_launch<128, 128, 4, 2, 2>(p, s);
+  if (force == 11) return v2_launch<256, 128, 4, 2, 2>(p, s);
+  if (force == 12) return v2_launch<256, 64, 4, 2, 2>(p, s);
+  if (force == 13) return v2_launch<128, 64, 4, 2, 2>(p, s);
+  if (force == 4) return v2_launch<128, 64, 2, 2, 2>(p, s);
+  if (force == 5) return v2_launch<64, 64, 2, 2, 2>(p, s);
+  if (tiles_of(p, 128, 64) >= 2048) {
+    const int n128 = ((p.N + 127) / 128) * 128;
+    if (tiles_of(p, 128, 128) >= 1536 && (n128 - p.N) * 100 <= 8 * p.N) return v2_launch<128, 128, 4, 2, 2>(p, s);
+    return v2_launch<128, 64, 4, 2, 2>(p, s);
+  }
   return v2_launch<64, 64, 2, 2, 2>(p, s);
 }

@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sam2_opt_amd.native import Engine
 B = int(os.environ.get("B", "8"))
+MODE = int(os.environ.get("MODE", "-1"))
 HINTS = [int(x) for x in os.environ.get("HINTS", "0").split(",")]
 shapes = [
     ("s1 qkv", B * 65536, 432, 144, 0), ("s1 proj", B * 65536, 144, 144, 1), ("s1 fc1", B * 65536, 576, 144, 0), ("s1 fc2", B * 65536, 144, 576, 1),
@@ -17,6 +18,6 @@ eng = Engine("large", state_dict=None)
 for name, M, N, K, mode in shapes:
     row = f"{name:8s} M={M:7d} N={N:5d} K={K:5d} m{mode}:"
     for h in HINTS:
-        ms = eng.debug_gemm_bench(M, N, K, 10, mode | (h << 4))
+        ms = eng.debug_gemm_bench(M, N, K, 10, (MODE if MODE >= 0 else mode) | (h << 4))
         row += f"  h{h}: {ms*1e3:8.1f}us {2.0*M*N*K/ms/1e9:7.1f}TF"
     print(row, flush=True)
