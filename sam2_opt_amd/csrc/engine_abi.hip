@@ -183,9 +183,14 @@ static int sam_heads_finish(sam2mi_ctx* ctx, hipStream_t s, int multimask, int b
   CHK(select_mask_launch(ctx->d_masks, ctx->d_iou, ctx->d_obj, ctx->d_mtok, multimask, ctx->d_best + 2, 0.05f, 0.98f,
                          ctx->d_low_multi, bk.low_mask, ctx->d_tok_sel, ctx->d_best, ctx->d_iou_sel, s));
   // obj_ptr = MLP3(token) gated by the object score (sam2_base_official.py:474-484)
-  CHK(small_linear_launch(ctx->d_tok_sel, 256, ctx->ptr_proj[0].w, ctx->ptr_proj[0].b, ctx->d_t1, 256, nullptr, 0, 1, 256, 256, 2, s));
-  CHK(small_linear_launch(ctx->d_t1, 256, ctx->ptr_proj[1].w, ctx->ptr_proj[1].b, ctx->d_t2, 256, nullptr, 0, 1, 256, 256, 2, s));
-  CHK(small_linear_launch(ctx->d_t2, 256, ctx->ptr_proj[2].w, ctx->ptr_proj[2].b, bk.obj_ptr, 256, nullptr, 0, 1, 256, 256, 0, s));
+  {
+    Mlp3Batch B;
+    B.n = 1;
+    Mlp3Group& g = B.g[0];
+    g.x = ctx->d_tok_sel; g.y = bk.obj_ptr; g.n_out = 256; g.sigmoid_out = 0;
+    for (int i = 0; i < 3; ++i) { g.W[i] = ctx->ptr_proj[i].w; g.b[i] = ctx->ptr_proj[i].b; }
+    CHK(mlp3_launch(B, s));
+  }
   CHK(gate_obj_ptr_launch(bk.obj_ptr, ctx->no_obj_ptr, ctx->d_obj, 256, s));
   CHK(hipMemcpyAsync(bk.obj_score, ctx->d_obj, sizeof(float), hipMemcpyDeviceToDevice, s));
   if (out) {

@@ -101,6 +101,17 @@ static int tok_linear(sam2mi_ctx* ctx, hipStream_t s, const float* x, int ldx, c
   CHK(small_linear_launch(x, ldx, L.w, L.b, y, ldy, res, ldres, T, L.N, L.K, act, s));
   return 0;
 }
+static SmallLin mk_lin(const float* x, int ldx, const Lin32& L, float* y, int ldy, int T, int act, const float* res = nullptr,
+                       int ldres = 0) {
+  return SmallLin{x, L.w, L.b, y, res, ldx, ldy, ldres, T, L.N, L.K, act};
+}
+static Mlp3Group mk_mlp3(const float* x, const Lin32* L, float* y, int sigmoid_out) {
+  Mlp3Group g;
+  g.x = x; g.y = y; g.n_out = L[2].N; g.sigmoid_out = sigmoid_out;
+  for (int i = 0; i < 3; ++i) { g.W[i] = L[i].w; g.b[i] = L[i].b; }
+  return g;
+}
+static bool mlp3_ok(const Lin32* L) { return L[0].K == 256 && L[0].N == 256 && L[1].K == 256 && L[1].N == 256 && L[2].K == 256; }
 static int tok_ln(sam2mi_ctx* ctx, hipStream_t s, float* x, const Norm& n, int T) {
   CHK(layernorm_launch(x, 256, n.w, n.b, 1e-5f, T, 256, nullptr, 0, x, 256, 0, s));
   return 0;
@@ -156,9 +167,14 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* keys_tok, const
       CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, T, 256, nullptr, 0, ctx->d_tokpe, 256, s));
       qin = ctx->d_tokpe;
     }
-    CHKI(tok_linear(ctx, s, qin, 256, L.self_attn.q, ctx->d_t1, 256, T, 0));
-    CHKI(tok_linear(ctx, s, qin, 256, L.self_attn.k, ctx->d_t2, 256, T, 0));
-    CHKI(tok_linear(ctx, s, q, 256, L.self_attn.v, ctx->d_t3, 256, T, 0));
+    {
+      SmallLinBatch B;
+      B.n = 3;
+      B.d[0] = mk_lin(qin, 256, L.self_attn.q, ctx->d_t1, 256, T, 0);
+      B.d[1] = mk_lin(qin, 256, L.self_attn.k, ctx->d_t2, 256, T, 0);
+      B.d[2] = mk_lin(q, 256, L.self_attn.v, ctx->d_t3, 256, T, 0);
+      CHK(small_linear_batch_launch(B, s));
+    }
     CHK(small_attn_launch(ctx->d_t1, 256, ctx->d_t2, 256, ctx->d_t3, 256, ctx->d_t4, 256, T, T, 8, 32, 1, 0, 0, 0, s));
     CHKI(tok_linear(ctx, s, ctx->d_t4, 256, L.self_attn.o, q, 256, T, 0, l > 0 ? q : nullptr, 256));
     CHKI(tok_ln(ctx, s, q, L.n1, T));
@@ -179,8 +195,13 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* keys_tok, const
       p.out32 = ctx->d_big1; p.ld32 = 128;
       CHKI(run_gemm(ctx, s, p));
       CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, T, 256, nullptr, 0, ctx->d_tokpe, 256, s));
-      CHKI(tok_linear(ctx, s, ctx->d_tokpe, 256, L.i2t_k, ctx->d_t1, 128, T, 0));
-      CHKI(tok_linear(ctx, s, q, 256, L.i2t_v, ctx->d_t2, 128, T, 0));
+      {
+        SmallLinBatch B;
+        B.n = 2;
+        B.d[0] = mk_lin(ctx->d_tokpe, 256, L.i2t_k, ctx->d_t1, 128, T, 0);
+        B.d[1] = mk_lin(q, 256, L.i2t_v, ctx->d_t2, 128, T, 0);
+        CHK(small_linear_batch_launch(B, s));
+      }
       CHK(small_attn_launch(ctx->d_big1, 128, ctx->d_t1, 128, ctx->d_t2, 128, ctx->d_big2, 128, 4096, T, 8, 16, 1, 0, 0, 0, s));
       CHK(cast_add_launch(ctx->d_big2, 128, nullptr, 0, 0, 0.f, 4096, 128, ctx->d_big16, 128, nullptr, 0, s));
       GemmParams o = lin_params(ctx->d_big16, 128, 4096, L.i2t_o);
@@ -207,12 +228,16 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* keys_tok, const
     CHKI(run_gemm(ctx, s, p2));
     CHK(upscale_glue_launch(ctx->d_g, 128, 32, ctx->dc2_b, hr0_tok, nullptr, nullptr, ctx->d_up2_16, s));
   }
-  // ---- hyper-network MLPs on the 4 mask tokens -> [4, 32]
-  for (int i = 0; i < 4; ++i) {
-    const float* tk = q + (size_t)(2 + i) * 256;
-    CHKI(tok_linear(ctx, s, tk, 256, ctx->hyper[i][0], ctx->d_t1, 256, 1, 2));
-    CHKI(tok_linear(ctx, s, ctx->d_t1, 256, ctx->hyper[i][1], ctx->d_t2, 256, 1, 2));
-    CHKI(tok_linear(ctx, s, ctx->d_t2, 256, ctx->hyper[i][2], ctx->d_hyper + i * 32, 32, 1, 0));
+  // ---- hyper-network MLPs on the 4 mask tokens -> [4, 32], IoU head (sigmoid) and object-score head: one launch
+  {
+    if (!mlp3_ok(ctx->hyper[0]) || !mlp3_ok(ctx->iou_head) || !mlp3_ok(ctx->obj_head))
+      return sam2mi_set_error(ctx, "decoder_forward", "output MLPs must be 256-256-256-n");
+    Mlp3Batch B;
+    B.n = 6;
+    for (int i = 0; i < 4; ++i) B.g[i] = mk_mlp3(q + (size_t)(2 + i) * 256, ctx->hyper[i], ctx->d_hyper + i * 32, 0);
+    B.g[4] = mk_mlp3(q + 256, ctx->iou_head, ctx->d_iou, 1);
+    B.g[5] = mk_mlp3(q, ctx->obj_head, ctx->d_obj, 0);
+    CHK(mlp3_launch(B, s));
   }
   CHK(cast_add_launch(ctx->d_hyper, 32, nullptr, 0, 0, 0.f, 4, 32, ctx->d_hyper16, 32, nullptr, 0, s));
   // masks[i, pix] = sum_c hyper[i, c] * up[pix, c]   (GEMM over pixels, stored transposed)
@@ -222,13 +247,6 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* keys_tok, const
     p.n_split = 0; p.outT32 = ctx->d_masks; p.ldT32 = 65536;
     CHKI(run_gemm(ctx, s, p));
   }
-  // ---- IoU head (sigmoid) and object-score head
-  CHKI(tok_linear(ctx, s, q + 256, 256, ctx->iou_head[0], ctx->d_t1, 256, 1, 2));
-  CHKI(tok_linear(ctx, s, ctx->d_t1, 256, ctx->iou_head[1], ctx->d_t2, 256, 1, 2));
-  CHKI(tok_linear(ctx, s, ctx->d_t2, 256, ctx->iou_head[2], ctx->d_iou, 4, 1, 3));
-  CHKI(tok_linear(ctx, s, q, 256, ctx->obj_head[0], ctx->d_t1, 256, 1, 2));
-  CHKI(tok_linear(ctx, s, ctx->d_t1, 256, ctx->obj_head[1], ctx->d_t2, 256, 1, 2));
-  CHKI(tok_linear(ctx, s, ctx->d_t2, 256, ctx->obj_head[2], ctx->d_obj, 1, 1, 0));
   return 0;
 }
 

@@ -7,35 +7,88 @@ namespace {
 constexpr float NO_OBJ_SCORE = -1024.f;     // modeling/sam2_base_official.py:21
 constexpr float TWO_PI = 6.283185307179586f;
 
-// y[t, n] for all t: one wave per n
-__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
-                                                           const float* __restrict__ b, float* y, int ldy, const float* res,
-                                                           int ldres, int T, int N, int K, int act) {
+// y[t, n] for all t: one wave per output column n, lanes over K (16-B loads); blockIdx.y picks one of up to 4
+// independent linears so that e.g. the q/k/v projections of a token attention go out as one launch
+__global__ __launch_bounds__(256) void small_linear_kernel(const SmallLinBatch B) {
+  const SmallLin& D = B.d[blockIdx.y];
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (n >= N) return;
-  const float* wr = W + (size_t)n * K;
-  for (int t0 = 0; t0 < T; t0 += 8) {
+  if (n >= D.N) return;
+  const float* wr = D.W + (size_t)n * D.K;
+  const bool vec = ((D.K | D.ldx) & 3) == 0 && (((uintptr_t)D.x | (uintptr_t)D.W) & 15) == 0;
+  for (int t0 = 0; t0 < D.T; t0 += 8) {
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int k = lane; k < K; k += 64) {
-      const float wv = wr[k];
+    if (vec) {
+      for (int k = lane * 4; k < D.K; k += 256) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (t0 + j < T) acc[j] += wv * x[(size_t)(t0 + j) * ldx + k];
+        for (int j = 0; j < 8; ++j)
+          if (t0 + j < D.T) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(D.x + (size_t)(t0 + j) * D.ldx + k);
+            acc[j] += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+          }
+      }
+    } else {
+      for (int k = lane; k < D.K; k += 64) {
+        const float wv = wr[k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (t0 + j < D.T) acc[j] += wv * D.x[(size_t)(t0 + j) * D.ldx + k];
+      }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float v = wave_sum(acc[j]);
-      if (lane == 0 && t0 + j < T) {
-        float o = v + (b ? b[n] : 0.f);
-        if (act == 2) o = fmaxf(o, 0.f);
-        else if (act == 3) o = 1.f / (1.f + expf(-o));
-        if (res) o += res[(size_t)(t0 + j) * ldres + n];
-        y[(size_t)(t0 + j) * ldy + n] = o;
+      if (lane == 0 && t0 + j < D.T) {
+        float o = v + (D.b ? D.b[n] : 0.f);
+        if (D.act == 2) o = fmaxf(o, 0.f);
+        else if (D.act == 3) o = 1.f / (1.f + expf(-o));
+        if (D.res) o += D.res[(size_t)(t0 + j) * D.ldres + n];
+        D.y[(size_t)(t0 + j) * D.ldy + n] = o;
       }
     }
+  }
+}
+
+// 3-layer MLP 256 -> 256 -> 256 -> n_out (ReLU between, optional sigmoid at the end) on ONE row per group, one
+// 1024-thread workgroup per group (blockIdx.x): the hyper-network MLPs, the IoU / object-score heads and the
+// object-pointer projection (sam/mask_decoder.py:290-303, sam2_base_official.py:474) are 3 dependent mat-vecs
+// each - as separate launches they cost 3 launch latencies apiece, here one launch covers all of them.
+__global__ __launch_bounds__(1024) void mlp3_kernel(const Mlp3Batch B) {
+  const Mlp3Group& G = B.g[blockIdx.x];
+  __shared__ __attribute__((aligned(16))) float buf[2][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // 16 waves
+  if (tid < 256) buf[0][tid] = G.x[tid];
+  __syncthreads();
+#pragma unroll 1
+  for (int layer = 0; layer < 3; ++layer) {
+    const float* W = G.W[layer];
+    const float* b = G.b[layer];
+    const int N = layer == 2 ? G.n_out : 256;
+    const float* in = buf[layer & 1];
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(in + lane * 4);
+    // each wave: outputs wave, wave+16, ... ; 8 rows of W in flight per wave
+    for (int o0 = wave; o0 < N; o0 += 16 * 8) {
+      f32x4 w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int o = o0 + 16 * u;
+        w[u] = (o < N) ? *reinterpret_cast<const f32x4*>(W + (size_t)o * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int o = o0 + 16 * u;
+        float v = wave_sum(w[u][0] * xv[0] + w[u][1] * xv[1] + w[u][2] * xv[2] + w[u][3] * xv[3]);
+        if (lane == 0 && o < N) {
+          v += b ? b[o] : 0.f;
+          if (layer < 2) buf[(layer + 1) & 1][o] = fmaxf(v, 0.f);
+          else G.y[o] = G.sigmoid_out ? 1.f / (1.f + expf(-v)) : v;
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -199,9 +252,25 @@ __global__ void ptr_tokens_kernel(const PtrTokParams p) {
 }
 }  // namespace
 
+hipError_t small_linear_batch_launch(const SmallLinBatch& B, hipStream_t s) {
+  if (B.n < 1 || B.n > 4) return hipErrorInvalidValue;
+  int maxN = 0;
+  for (int i = 0; i < B.n; ++i) maxN = B.d[i].N > maxN ? B.d[i].N : maxN;
+  small_linear_kernel<<<dim3((maxN + 3) / 4, B.n), dim3(256), 0, s>>>(B);
+  return hipGetLastError();
+}
 hipError_t small_linear_launch(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, const float* res,
                                int ldres, int T, int N, int K, int act, hipStream_t s) {
-  small_linear_kernel<<<dim3((N + 3) / 4), dim3(256), 0, s>>>(x, ldx, W, b, y, ldy, res, ldres, T, N, K, act);
+  SmallLinBatch B;
+  B.n = 1;
+  B.d[0] = SmallLin{x, W, b, y, res, ldx, ldy, ldres, T, N, K, act};
+  return small_linear_batch_launch(B, s);
+}
+hipError_t mlp3_launch(const Mlp3Batch& B, hipStream_t s) {
+  if (B.n < 1 || B.n > 8) return hipErrorInvalidValue;
+  for (int i = 0; i < B.n; ++i)
+    if (B.g[i].n_out < 1 || B.g[i].n_out > 256) return hipErrorInvalidValue;
+  mlp3_kernel<<<dim3(B.n), dim3(1024), 0, s>>>(B);
   return hipGetLastError();
 }
 hipError_t point_embed_launch(const float* pts, const int* labels, int Np, const float* gauss, const float* point_emb4,

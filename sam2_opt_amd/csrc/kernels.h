@@ -44,6 +44,18 @@ hipError_t dwconv7_launch(const float* in, int H, int C, const float* w, const f
 // y[t, n] = act(sum_k x[t, k] W[n, k] + b[n]) (+ res[t, n]);  f32 everywhere, T <= 64.  act: 0 none, 2 relu, 3 sigmoid
 hipError_t small_linear_launch(const float* x, int ldx, const float* W, const float* b, float* y, int ldy,
                                const float* res, int ldres, int T, int N, int K, int act, hipStream_t s);
+// up to 4 independent small linears in one launch (same semantics per entry)
+struct SmallLin {
+  const float* x; const float* W; const float* b; float* y; const float* res;
+  int ldx, ldy, ldres, T, N, K, act;
+};
+struct SmallLinBatch { SmallLin d[4]; int n; };
+hipError_t small_linear_batch_launch(const SmallLinBatch& B, hipStream_t s);
+// up to 8 fused 3-layer MLPs (256 -> 256 -> 256 -> n_out, ReLU, ReLU, optional sigmoid) on one row each, one launch:
+//   y[0..n_out) = act(W2 relu(W1 relu(W0 x + b0) + b1) + b2);  W row-major [out, 256] f32
+struct Mlp3Group { const float* x; const float* W[3]; const float* b[3]; float* y; int n_out; int sigmoid_out; };
+struct Mlp3Batch { Mlp3Group g[8]; int n; };
+hipError_t mlp3_launch(const Mlp3Batch& B, hipStream_t s);
 // sparse point embeddings (PromptEncoder._embed_points): pts [Np,2] px, labels [Np] -> out [Np+1, 256] (pad point appended)
 hipError_t point_embed_launch(const float* pts, const int* labels, int Np, const float* gauss, const float* point_emb4,
                               const float* not_a_point, float image_size, float* out, hipStream_t s);
