@@ -158,6 +158,8 @@ int sam2mi_debug_hiera_attention(sam2mi_ctx* ctx, void* stream, const float* q, 
 int sam2mi_debug_flash256(sam2mi_ctx* ctx, void* stream, const float* q, const float* k, const float* v, int Nq, int Nk, float* out);
 int sam2mi_debug_hiera_block(sam2mi_ctx* ctx, void* stream, int block_idx, const float* x_nhwc, int B, float* out_nhwc);
 int sam2mi_debug_gemm_bench(sam2mi_ctx* ctx, void* stream, int M, int N, int K, int iters, int mode, float* ms_out);
+/* time `iters` launches of the d=256 flash attention (+ combine) on random f16 operands; ms per launch */
+int sam2mi_debug_flash_bench(sam2mi_ctx* ctx, void* stream, int Nq, int Nk, int iters, float* ms_out);
 int sam2mi_debug_read(sam2mi_ctx* ctx, void* stream, const char* name, float* out, int64_t count);
 
 #ifdef __cplusplus

@@ -30,6 +30,7 @@ struct Flash256Params {
 };
 hipError_t flash256_launch(const Flash256Params& p, hipStream_t stream);
 hipError_t flash256_init();   // dynamic-LDS attribute, once
+int flash256_pick_splits(int Nq, int Nk);   // KV splits that fill the chip once (<= 16: the size of the partial buffers)
 
 // ---- tiny fp32 attentions of the two-way mask decoder (attn_small.hip)
 // q [Tq, ldq], k/v [Tk, ld], heads x hd, out [Tq, ldo]; all f32.  softmax(q k^T / sqrt(hd)) v

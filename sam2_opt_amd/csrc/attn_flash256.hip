@@ -16,6 +16,7 @@
 //   V^T [256 d  ][ 4 x 16-B chunks]: slot pc of row d holds chunk pc ^ ((d >> 2) & 3) (ds_read_b64, 2-way)
 // The O accumulator is rescaled only when some query of the wave saw a new running maximum.
 #include "attn.h"
+#include <cstdlib>
 
 namespace {
 constexpr int D = 256;
@@ -155,6 +156,255 @@ __global__ __launch_bounds__(256, 2) void flash256_kernel(const Flash256Params p
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v3: one workgroup per CU, one wave per SIMD (up to 512 registers per lane).  The 2-waves-per-SIMD kernel above is
+// register-starved (O 128 + Q 64 VGPRs of 256): the compiler serialises every K-fragment ds_read with the MFMA that
+// consumes it, so each MFMA waits a full LDS round trip.  Here a wave still owns 32 queries but has room to keep a
+// whole tile of K fragments (64 VGPRs) and V^T fragments in flight, and the loop is software-pipelined across tiles:
+//     iteration i:  softmax(S_i) [VALU]  ||  S_{i+1} = K_{i+1} Q^T [MFMA, LDS]  ->  O^T += V_i^T P_i^T [MFMA, LDS]
+// K/V^T tiles travel through a 4-stage LDS ring (LDS-DMA, counted vmcnt: one tile always stays in flight across the
+// barrier, none is ever drained in the loop).
+//   * K rows are read PERMUTED: MFMA row i of S^T holds key pi(i) = i with bits 2 and 3 swapped.  The P^T values a lane
+//     owns (accumulator rows (r&3) + 8(r>>2) + 4 fh) are then exactly keys 16 ks + 8 fh + 0..7 in B-operand order, so
+//     the matching V^T fragment is ONE contiguous ds_read_b128 of the natural-order V^T row.
+//   * Keys past Nk (only in the last tile) are masked through the INITIAL accumulator (-1e30 instead of 0).
+constexpr int NST = 4;
+// v3 LDS K image: piece kp (key rows 2kp, 2kp+1; 1 KiB) sits at kp * 1056: the 32-B pad rotates successive row pairs over
+// the 16 bank slots and the DMA source swaps the two 16-B halves of every 32 B in odd rows, so a 16-lane ds_read_b128
+// group (8 row pairs, one chunk) is conflict-free AND chunk 2 ks + fh of row r is at  base(r, fh) + 32 ks  - an
+// immediate offset, one address register per wave instead of sixteen.
+constexpr int K3_PIECE = 1056;
+constexpr int K3_TILE_B = 16 * K3_PIECE;             // 16896
+constexpr int STAGE3_B = K3_TILE_B + V_TILE_B;       // 33280
+
+static __device__ __forceinline__ int pi23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+template <int N>
+static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ABL != 0: timing ablations for tuning (results are wrong): 1 no LDS-DMA in the loop, 2 no barrier / vmcnt wait,
+// 3 no exponentials, 4 no P.V product, 5 no next-tile QK product
+// MASK: Nk is not a multiple of 32 (keys past Nk in the last tile are masked when the score chains are summed)
+template <int ABL, bool MASK>
+__global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, fh = lane >> 5;
+  // 1-D grid, XCD-aware: the 8 XCDs take contiguous chunks of (split, query block) pairs, split-major, so the
+  // workgroups that share an L2 walk the SAME K/V^T split together (with 8 splits: one split per XCD).  Dealt
+  // round-robin instead, every XCD streams the whole K/V^T through its 4 MiB L2 and the kernel is Infinity-Cache bound.
+  const int qblocks = p.Nq >> 7;
+  const int pair = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = pair / qblocks;
+  const int q0 = (pair % qblocks) * 128 + wave * 32;
+  const int ntiles = (p.Nk + 31) / 32;
+  const int per = (ntiles + p.splits - 1) / p.splits;
+  const int t_lo = split * per, t_hi = min(ntiles, t_lo + per);
+  const int n = max(t_hi - t_lo, 0);
+
+  // Q fragments first (their loads retire before any LDS-DMA piece: vector memory returns in order)
+  half8 qf[16];
+  {
+    const half_t* qp = p.q + (size_t)(q0 + fr) * p.ldq + fh * 8;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) qf[s] = *reinterpret_cast<const half8*>(qp + s * 16);
+  }
+  int k_src[4], v_src[4];          // element offsets (fit 32 bits)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int kp = wave * 4 + j;                       // K piece 0..15: 2 key rows x 32 chunks
+    const int krow = kp * 2 + (lane >> 5), kpc = lane & 31;
+    k_src[j] = krow * p.ldk + ((kpc ^ (krow & 1)) << 3);
+    const int vp = wave * 4 + j;                       // V^T piece 0..15: 16 d rows x 4 chunks
+    const int vrow = vp * 16 + (lane >> 2), vpc = lane & 3;
+    v_src[j] = vrow * p.ldvT + ((vpc ^ ((vrow >> 2) & 3)) << 3);
+  }
+  auto issue = [&](int i) {                            // tile t_lo + i -> ring stage i % NST
+    char* sb = smem + (i % NST) * STAGE3_B;
+    const half_t* kb = p.k + (size_t)(t_lo + i) * 32 * p.ldk;
+    const half_t* vb = p.vT + (t_lo + i) * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + k_src[j]), (lds_ptr_t)(sb + (wave * 4 + j) * K3_PIECE), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vb + v_src[j]), (lds_ptr_t)(sb + K3_TILE_B + (wave * 4 + j) * 1024), 16, 0, 0);
+    }
+  };
+  // K fragments of ring tile i (rows permuted by pi), 8 k-steps at a time.  Every batch of LDS reads is pinned in
+  // front of the MFMAs it feeds (sched_barrier): left alone, the scheduler sinks each ds_read next to its MFMA to
+  // save registers and every MFMA then waits a full LDS round trip.
+  const int krow = pi23(fr);
+  const int krow_off = (krow >> 1) * K3_PIECE + (krow & 1) * 512 + ((fh ^ (krow & 1)) << 4);
+  struct F8 { half8 f[8]; };
+  auto read_k8 = [&](int i, int half) {
+    const char* sK = smem + (i % NST) * STAGE3_B + krow_off;
+    F8 k;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k.f[j] = *reinterpret_cast<const half8*>(sK + (8 * half + j) * 32);
+    return k;
+  };
+  // V^T fragments of ring tile i: row d = 32 t + fr, keys 16 ks + 8 fh .. + 7 = 16-B chunk 2 ks + fh; t = 4 half .. + 3
+  const int vsw = (fr >> 2) & 3;                       // ((32 t + fr) >> 2) & 3
+  auto read_v8 = [&](int i, int half) {
+    const char* sV = smem + (i % NST) * STAGE3_B + K3_TILE_B + fr * 64 + half * 8192;
+    F8 v;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      v.f[2 * t] = *reinterpret_cast<const half8*>(sV + t * 2048 + (((0 + fh) ^ vsw) << 4));
+      v.f[2 * t + 1] = *reinterpret_cast<const half8*>(sV + t * 2048 + (((2 + fh) ^ vsw) << 4));
+    }
+    return v;
+  };
+  // two independent MFMA chains over d (zero start); keys past Nk are masked when the chains are summed
+  auto qk_init = [&](f32x16& sa, f32x16& sb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sa[r] = sb[r] = 0.f;
+  };
+  auto qk_sum = [&](const f32x16& sa, const f32x16& sb, int nvalid) {
+    f32x16 r16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) r16[r] = (!MASK || pi23(acc_row(r, lane)) < nvalid) ? sa[r] + sb[r] : -1e30f;
+    return r16;
+  };
+  auto qk8 = [&](const F8& k, int half, f32x16& sa, f32x16& sb) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      sa = mfma32(k.f[j], qf[8 * half + j], sa);
+      sb = mfma32(k.f[j + 1], qf[8 * half + j + 1], sb);
+    }
+  };
+
+  f32x16 o[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  // Deferred rescale: probabilities are taken against a per-query REFERENCE maximum m_ref that is only raised when
+  // some query of the wave exceeds it by more than RESCALE_THR (log2 domain; p <= 2^THR fits f16 comfortably).  The
+  // O *= alpha pass then lives in the OUTER loop: inside the inner loop O is touched by MFMAs only, so the compiler
+  // keeps the 128 accumulator registers where the MFMAs want them instead of shuttling them every tile.
+  constexpr float RESCALE_THR = 8.f;
+  float m_ref = -1e30f, l_run = 0.f;
+  auto rowmax = [&](const f32x16& s) {
+    float t = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) t = fmaxf(t, s[r]);
+    return fmaxf(t, __shfl_xor(t, 32, 64));
+  };
+
+  if (n > 0) {
+    issue(0);
+    if (n > 1) issue(1);
+    if (n > 2) issue(2);
+    if (n > 2) wait_vm<16>();
+    else if (n > 1) wait_vm<8>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    f32x16 s;
+    {
+      const F8 ka = read_k8(0, 0);
+      const F8 kb = read_k8(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 sa, sb;
+      qk_init(sa, sb);
+      qk8(ka, 0, sa, sb);
+      qk8(kb, 1, sa, sb);
+      s = qk_sum(sa, sb, p.Nk - t_lo * 32);
+    }
+    float tmax = rowmax(s);
+    int i = 0;
+    for (;;) {
+      {                                                  // raise the reference maximum (first entry: from -1e30, O = 0)
+        const float m_new = fmaxf(m_ref, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_ref - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        m_ref = m_new;
+      }
+      bool done = false;
+#pragma nounroll
+      for (;;) {
+        // here: s / tmax belong to tile i and tmax <= m_ref + RESCALE_THR on every lane
+        // tile i+1 landed (tile i+2 may stay in flight); every wave is past tile i-1 -> stage (i-1) % NST is free
+        if (ABL != 2) {
+          if (i + 2 < n) wait_vm<8>();
+          else wait_vm<0>();
+          __builtin_amdgcn_s_barrier();
+        }
+        if (ABL != 1 && i + 3 < n) issue(i + 3);
+        // next tile's scores (garbage past the last tile: never used) run beside this tile's exponentials
+        const F8 ka = read_k8(i + 1, 0);
+        const F8 kb = read_k8(i + 1, 1);
+        const F8 va = read_v8(i, 0);
+        const F8 vb = read_v8(i, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 sa, sb;
+        qk_init(sa, sb);
+        if (ABL != 5) {
+          qk8(ka, 0, sa, sb);
+          qk8(kb, 1, sa, sb);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(ka.f[j]), "v"(kb.f[j]));
+        }
+        float psum = 0.f;
+        half8 pf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = ABL == 3 ? s[r] - m_ref : __builtin_amdgcn_exp2f(s[r] - m_ref);
+          psum += pv;
+          pf[r >> 3][r & 7] = (half_t)pv;
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run += psum;
+        // ---- O^T += V^T P^T, beside the mask / row maximum of the next tile's scores
+        if (ABL != 4) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            o[t] = mfma32(va.f[2 * t], pf[0], o[t]);
+            o[t] = mfma32(va.f[2 * t + 1], pf[1], o[t]);
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            o[4 + t] = mfma32(vb.f[2 * t], pf[0], o[4 + t]);
+            o[4 + t] = mfma32(vb.f[2 * t + 1], pf[1], o[4 + t]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(va.f[j]), "v"(vb.f[j]));
+          asm volatile("" ::"v"(pf[0]), "v"(pf[1]));
+        }
+        s = qk_sum(sa, sb, p.Nk - (t_lo + i + 1) * 32);
+        tmax = rowmax(s);
+        ++i;
+        if (i >= n) { done = true; break; }
+        if (__any(tmax > m_ref + RESCALE_THR)) break;
+      }
+      if (done) break;
+    }
+  }
+  const float m_run = m_ref;
+
+  // ---- partial results
+  const int q = q0 + fr;
+  float* op = p.o_part + ((size_t)split * p.Nq + q) * D;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = {o[t][4 * g], o[t][4 * g + 1], o[t][4 * g + 2], o[t][4 * g + 3]};
+      *reinterpret_cast<f32x4*>(op + t * 32 + 8 * g + 4 * fh) = v;
+    }
+  if (fh == 0) {
+    float* ml = p.ml_part + ((size_t)split * p.Nq + q) * 2;
+    ml[0] = m_run;
+    ml[1] = l_run;
+  }
+}
+
 // 64 threads per query (4 channels each), 4 queries per workgroup
 __global__ __launch_bounds__(256) void flash256_combine_kernel(const Flash256Params p) {
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6), d = (threadIdx.x & 63) * 4;
@@ -176,12 +426,45 @@ __global__ __launch_bounds__(256) void flash256_combine_kernel(const Flash256Par
 }  // namespace
 
 hipError_t flash256_init() {
+  const void* v3[7] = {reinterpret_cast<const void*>(&flash256_v3_kernel<0, false>), reinterpret_cast<const void*>(&flash256_v3_kernel<0, true>),
+                       reinterpret_cast<const void*>(&flash256_v3_kernel<1, true>), reinterpret_cast<const void*>(&flash256_v3_kernel<2, true>),
+                       reinterpret_cast<const void*>(&flash256_v3_kernel<3, true>), reinterpret_cast<const void*>(&flash256_v3_kernel<4, true>),
+                       reinterpret_cast<const void*>(&flash256_v3_kernel<5, true>)};
+  for (int i = 0; i < 7; ++i) {
+    hipError_t e = hipFuncSetAttribute(v3[i], hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE3_B);
+    if (e != hipSuccess) return e;
+  }
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&flash256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B);
+}
+
+// v3 runs one 128-query workgroup per CU: pick the KV split count that makes the grid one full wave of 256 workgroups
+int flash256_pick_splits(int Nq, int Nk) {
+  const int tiles = (Nk + 31) / 32, qblocks = Nq / 128 > 0 ? Nq / 128 : 1;
+  int s = (256 + qblocks - 1) / qblocks;
+  if (s > 16) s = 16;
+  if (s > tiles) s = tiles;
+  return s < 1 ? 1 : s;
 }
 
 hipError_t flash256_launch(const Flash256Params& p, hipStream_t stream) {
   if (p.Nq % 128 || p.Nk <= 0 || p.splits <= 0 || (p.ldq & 7) || (p.ldk & 7) || (p.ldvT & 7) || (p.ldout & 3)) return hipErrorInvalidValue;
-  flash256_kernel<<<dim3(p.Nq / 128, p.splits), dim3(256), 2 * STAGE_B, stream>>>(p);
+  static const bool use_v2 = getenv("SAM2MI_FLASH_V2") != nullptr;      // A/B switch: the 2-waves-per-SIMD kernel
+  if (use_v2) flash256_kernel<<<dim3(p.Nq / 128, p.splits), dim3(256), 2 * STAGE_B, stream>>>(p);
+  else {
+    static const int abl = getenv("SAM2MI_FLASH_ABL") ? atoi(getenv("SAM2MI_FLASH_ABL")) : 0;     // tuning only
+    const dim3 grid((p.Nq / 128) * p.splits), block(256);
+    const size_t lds = NST * STAGE3_B;
+    switch (abl) {
+      case 1: flash256_v3_kernel<1, true><<<grid, block, lds, stream>>>(p); break;
+      case 2: flash256_v3_kernel<2, true><<<grid, block, lds, stream>>>(p); break;
+      case 3: flash256_v3_kernel<3, true><<<grid, block, lds, stream>>>(p); break;
+      case 4: flash256_v3_kernel<4, true><<<grid, block, lds, stream>>>(p); break;
+      case 5: flash256_v3_kernel<5, true><<<grid, block, lds, stream>>>(p); break;
+      default:
+        if (p.Nk % 32) flash256_v3_kernel<0, true><<<grid, block, lds, stream>>>(p);
+        else flash256_v3_kernel<0, false><<<grid, block, lds, stream>>>(p);
+    }
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   flash256_combine_kernel<<<dim3(p.Nq / 4), dim3(256), 0, stream>>>(p);

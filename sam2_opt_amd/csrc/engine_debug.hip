@@ -82,7 +82,7 @@ extern "C" int sam2mi_debug_flash256(sam2mi_ctx* ctx, void* stream, const float*
   half_t* k16 = t.get<half_t>((size_t)NkP * 256);
   half_t* vT = t.get<half_t>((size_t)256 * NkP);
   half_t* o16 = t.get<half_t>((size_t)Nq * 256);
-  const int splits = std::max(1, std::min(16, ((Nk + 31) / 32) / 16));
+  const int splits = flash256_pick_splits(Nq, Nk);
   float* opart = t.get<float>((size_t)splits * Nq * 256);
   float* ml = t.get<float>((size_t)splits * Nq * 2);
   if (!q16 || !k16 || !vT || !o16 || !opart || !ml) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
@@ -171,6 +171,49 @@ extern "C" int sam2mi_debug_gemm_bench(sam2mi_ctx* ctx, void* stream, int M, int
   CHK(hipEventCreate(&e1));
   CHK(hipEventRecord(e0, s));
   for (int i = 0; i < iters; ++i) CHK(gemm_launch(p, s));
+  CHK(hipEventRecord(e1, s));
+  CHK(hipEventSynchronize(e1));
+  float ms = 0;
+  CHK(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / iters;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return 0;
+}
+
+// time `iters` launches of the d=256 flash attention + combine (pseudo-random f16 operands); ms per launch
+extern "C" int sam2mi_debug_flash_bench(sam2mi_ctx* ctx, void* stream, int Nq, int Nk, int iters, float* ms_out) {
+  if (!ctx) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  const int NkP = (Nk + 31) / 32 * 32;
+  Tmp t;
+  half_t* q16 = t.get<half_t>((size_t)Nq * 256);
+  half_t* k16 = t.get<half_t>((size_t)NkP * 256);
+  half_t* vT = t.get<half_t>((size_t)256 * NkP);
+  half_t* o16 = t.get<half_t>((size_t)Nq * 256);
+  const int splits = flash256_pick_splits(Nq, Nk);
+  float* opart = t.get<float>((size_t)splits * Nq * 256);
+  float* ml = t.get<float>((size_t)splits * Nq * 2);
+  const size_t nmax = (size_t)std::max(Nq, NkP) * 256;
+  float* tmp = t.get<float>(nmax);
+  if (!q16 || !k16 || !vT || !o16 || !opart || !ml || !tmp) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+  std::vector<float> h(nmax);
+  uint32_t x = 777u;
+  for (auto& v : h) { x = x * 1664525u + 1013904223u; v = (((x >> 9) & 0xFFFF) / 32768.0f - 1.0f) * 0.25f; }
+  CHK(hipMemcpy(tmp, h.data(), nmax * sizeof(float), hipMemcpyHostToDevice));
+  CHK(cast_add_launch(tmp, 256, nullptr, 0, 0, 0.f, Nq, 256, q16, 256, nullptr, 0, s));
+  CHK(cast_add_launch(tmp, 256, nullptr, 0, 0, 0.f, NkP, 256, k16, 256, nullptr, 0, s));
+  CHK(cast_add_launch(tmp, NkP, nullptr, 0, 0, 0.f, 256, NkP, vT, NkP, nullptr, 0, s));
+  Flash256Params f;
+  memset(&f, 0, sizeof(f));
+  f.q = q16; f.ldq = 256; f.k = k16; f.ldk = 256; f.vT = vT; f.ldvT = NkP; f.Nq = Nq; f.Nk = Nk; f.splits = splits;
+  f.o_part = opart; f.ml_part = ml; f.out = o16; f.ldout = 256; f.scale_log2e = 1.4426950408889634f / 16.f;
+  for (int i = 0; i < 2; ++i) CHK(flash256_launch(f, s));
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0));
+  CHK(hipEventCreate(&e1));
+  CHK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) CHK(flash256_launch(f, s));
   CHK(hipEventRecord(e1, s));
   CHK(hipEventSynchronize(e1));
   float ms = 0;

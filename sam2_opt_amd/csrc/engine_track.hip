@@ -5,13 +5,6 @@ static const float LOG2E = 1.4426950408889634f;
 
 static inline int ceil32(int v) { return (v + 31) / 32 * 32; }
 
-static int pick_splits(int Nk) {
-  const int tiles = (Nk + 31) / 32;
-  int s = tiles / 16;
-  if (s < 1) s = 1;
-  if (s > 16) s = 16;
-  return s;
-}
 
 // MemoryAttention.inference_memory_attention_torch (modeling/memory_attention.py:299-349) with
 // MemoryAttentionLayer.forward (:93-109) and RoPEAttention.forward (sam/transformer.py:345-424).
@@ -49,7 +42,7 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
       Flash256Params f;
       memset(&f, 0, sizeof(f));
       f.q = ctx->t_qk16; f.ldq = 512; f.k = ctx->t_qk16 + 256; f.ldk = 512; f.vT = ctx->t_vT16; f.ldvT = S;
-      f.Nq = S; f.Nk = S; f.splits = pick_splits(S); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
+      f.Nq = S; f.Nk = S; f.splits = flash256_pick_splits(S, S); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
       f.out = ctx->t_o16; f.ldout = C; f.scale_log2e = LOG2E / 16.f;
       CHKI(run_flash256(ctx, s, f));
     }
@@ -71,7 +64,7 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
       memset(&f, 0, sizeof(f));
       f.q = ctx->t_q16; f.ldq = C; f.k = ctx->t_kall16 + l * 256; f.ldk = 1024;
       f.vT = ctx->t_vTall16 + (size_t)l * 256 * NkP; f.ldvT = NkP;
-      f.Nq = S; f.Nk = Nk; f.splits = pick_splits(Nk); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
+      f.Nq = S; f.Nk = Nk; f.splits = flash256_pick_splits(S, Nk); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
       f.out = ctx->t_o16; f.ldout = C; f.scale_log2e = LOG2E / 16.f;
       CHKI(run_flash256(ctx, s, f));
     }

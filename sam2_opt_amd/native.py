@@ -20,7 +20,7 @@ EXPORTS = [
     "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_dense_pe", "sam2mi_video_encode",
     "sam2mi_video_click", "sam2mi_image_predict", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_resize_bilinear",
     "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
-    "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench",
+    "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench",
 ]
 
 
@@ -291,6 +291,11 @@ class Engine:
         out = self.new(*shape)
         self._check(self.lib.sam2mi_debug_read(self.h, self.stream, name.encode(), _ptr(out), C.c_int64(out.numel())), "sam2mi_debug_read")
         return out
+
+    def debug_flash_bench(self, Nq, Nk, iters=10) -> float:
+        ms = C.c_float()
+        self._check(self.lib.sam2mi_debug_flash_bench(self.h, self.stream, Nq, Nk, iters, C.byref(ms)), "sam2mi_debug_flash_bench")
+        return ms.value
 
     def debug_gemm_bench(self, M, N, K, iters=20, mode=0) -> float:
         ms = C.c_float()
