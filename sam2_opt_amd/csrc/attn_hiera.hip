@@ -10,6 +10,7 @@
 // head_dim 72 is padded in LDS/registers only: QK^T sums over 80 (5 MFMA k-steps, pad = 0),
 // PV produces 96 rows (3 MFMA row tiles) of which 72 are stored.
 #include "attn.h"
+#include <cstdlib>
 
 namespace {
 constexpr int HD = 72;
@@ -177,6 +178,209 @@ __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// v2 (shared-tile, unmasked case: stage-3 windows and the global blocks): same swapped products, but staged like the
+// d=256 kernel (attn_flash256.hip v3):
+//   * K / V^T tiles arrive by LDS-DMA into a 4-stage ring (counted vmcnt, one barrier per tile, never drained);
+//     K image dense [32 keys][9 x 16 B] (144-B rows are conflict-free for ds_read_b128 as they stand), V^T image
+//     [72 d][4 x 16 B] with the chunk index XOR-ed by (d >> 2) & 3 on the DMA source address;
+//   * K rows are read permuted (bits 2,3 of the key index swapped) so the V^T fragment that matches a lane's P^T
+//     values is one contiguous ds_read_b128;
+//   * iteration i runs S_{i+1} = K_{i+1} Q^T beside the exponentials of tile i, then O^T += V_i^T P_i^T;
+//   * the O rescale is deferred to an outer loop (reference maximum raised only past a threshold).
+// head_dim pad: k-step 4 has only 8 real columns - lanes of the upper half re-read chunk 8 against a zero Q fragment;
+// PV row tile 2 has 8 real rows - the other lanes read row 71 and their products are discarded.
+constexpr int H2_NST = 4;
+constexpr int H2_KT = 32 * 144;            // 4608 B
+constexpr int H2_VT = HD * 64;             // 4608 B
+constexpr int H2_STAGE = H2_KT + H2_VT;    // 9216 B
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+static __device__ __forceinline__ int h2_pi23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+template <int N>
+static __device__ __forceinline__ void h2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[H2_NST * H2_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int qtiles = p.GQ / 32;                       // multiple of 4
+  const int task = blockIdx.x * 4 + wave;             // the 4 waves: 4 consecutive query tiles of one (group, head)
+  const int qt = task % qtiles;
+  const int gh = task / qtiles;
+  const int head = gh % p.heads, grp = gh / p.heads;
+  const int n = p.GK / 32;                            // key tiles (every query sees the whole group)
+
+  // ---- Q fragments (B operand): lane holds Q[q = fr][d = 16 s + 8 fh + j]; pre-scaled by 72^-0.5 * log2(e)
+  const size_t qrow = (size_t)grp * p.GQ + qt * 32 + fr;
+  half8 qf[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    if (s == 4 && fh == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (half_t)0.f;
+    } else {
+      qf[s] = *reinterpret_cast<const half8*>(p.q + qrow * p.ldq + head * HD + s * 16 + fh * 8);
+    }
+  }
+
+  // ---- LDS-DMA sources.  288 K chunks + 288 V^T chunks per tile = 4.5 + 4.5 wave-instructions: wave w moves K chunks
+  // [64 w, 64 w + 64), V^T chunks likewise, and a third half-wave piece: chunks 256..287 of K (waves 0, 2) or of V^T
+  // (waves 1, 3) - written twice with identical bytes, so that every wave has exactly 3 pieces per tile in flight.
+  const half_t* kbase = p.k + ((size_t)grp * p.GK) * p.ldk + head * HD;
+  const half_t* vbase = p.vT + (size_t)head * HD * p.ldvT + (size_t)grp * p.GK;
+  auto k_off = [&](int c) { return (c / 9) * p.ldk + (c % 9) * 8; };                              // halfs from kbase (+ k0 rows)
+  auto v_off = [&](int c) { const int d = c >> 2, pc = c & 3; return d * p.ldvT + ((pc ^ ((d >> 2) & 3)) << 3); };
+  const int c_main = wave * 64 + lane, c_tail = 256 + (lane & 31);
+  const int ko_main = k_off(c_main), vo_main = v_off(c_main);
+  const bool tail_is_k = (wave & 1) == 0;
+  const int o_tail = tail_is_k ? k_off(c_tail) : v_off(c_tail);
+  auto issue = [&](int i) {
+    char* sb = smem + (i % H2_NST) * H2_STAGE;
+    const half_t* kb = kbase + (size_t)i * 32 * p.ldk;
+    const half_t* vb = vbase + i * 32;
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + ko_main), (lds_ptr_t)(sb + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vb + vo_main), (lds_ptr_t)(sb + H2_KT + wave * 1024), 16, 0, 0);
+    if (lane < 32)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)((tail_is_k ? kb : vb) + o_tail), (lds_ptr_t)(sb + (tail_is_k ? 0 : H2_KT) + 4096), 16, 0, 0);
+  };
+
+  // ---- fragment reads
+  const int krow = h2_pi23(fr);
+  const int k_base = krow * 144 + fh * 16, k_base4 = krow * 144 + 128;
+  struct KF { half8 f[5]; };
+  auto read_k = [&](int i) {
+    const char* sK = smem + (i % H2_NST) * H2_STAGE;
+    KF k;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) k.f[ks] = *reinterpret_cast<const half8*>(sK + k_base + ks * 32);
+    k.f[4] = *reinterpret_cast<const half8*>(sK + k_base4);
+    return k;
+  };
+  const int vsw = (fr >> 2) & 3;
+  const int v_row2 = min(64 + fr, HD - 1);            // row tile 2: rows past 71 alias row 71 (discarded products)
+  const int v_sw2 = (v_row2 >> 2) & 3;
+  struct VF { half8 f[6]; };
+  auto read_v = [&](int i) {
+    const char* sV = smem + (i % H2_NST) * H2_STAGE + H2_KT;
+    VF v;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      v.f[2 * t] = *reinterpret_cast<const half8*>(sV + (t * 32 + fr) * 64 + (((0 + fh) ^ vsw) << 4));
+      v.f[2 * t + 1] = *reinterpret_cast<const half8*>(sV + (t * 32 + fr) * 64 + (((2 + fh) ^ vsw) << 4));
+    }
+    v.f[4] = *reinterpret_cast<const half8*>(sV + v_row2 * 64 + (((0 + fh) ^ v_sw2) << 4));
+    v.f[5] = *reinterpret_cast<const half8*>(sV + v_row2 * 64 + (((2 + fh) ^ v_sw2) << 4));
+    return v;
+  };
+  auto qk = [&](const KF& k) {
+    f32x16 sa, sb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sa[r] = sb[r] = 0.f;
+    sa = mfma32(k.f[0], qf[0], sa);
+    sb = mfma32(k.f[1], qf[1], sb);
+    sa = mfma32(k.f[2], qf[2], sa);
+    sb = mfma32(k.f[3], qf[3], sb);
+    sa = mfma32(k.f[4], qf[4], sa);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sa[r] += sb[r];
+    return sa;
+  };
+  auto rowmax = [&](const f32x16& s) {
+    float t = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) t = fmaxf(t, s[r]);
+    return fmaxf(t, __shfl_xor(t, 32, 64));
+  };
+
+  f32x16 o[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+  constexpr float RESCALE_THR = 8.f;
+  float m_ref = -1e30f, l_run = 0.f;
+
+  issue(0);
+  if (n > 1) issue(1);
+  if (n > 2) issue(2);
+  if (n > 2) h2_wait_vm<6>();
+  else if (n > 1) h2_wait_vm<3>();
+  else h2_wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  f32x16 s;
+  {
+    const KF k0 = read_k(0);
+    __builtin_amdgcn_sched_barrier(0);
+    s = qk(k0);
+  }
+  float tmax = rowmax(s);
+  int i = 0;
+  for (;;) {
+    {                                                    // raise the reference maximum (first entry: from -1e30, O = 0)
+      const float m_new = fmaxf(m_ref, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_ref - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      m_ref = m_new;
+    }
+    bool done = false;
+#pragma nounroll
+    for (;;) {
+      // tile i+1 landed (tile i+2 may stay in flight); every wave is past tile i-1 -> its ring stage is free
+      if (i + 2 < n) h2_wait_vm<3>();
+      else h2_wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      if (i + 3 < n) issue(i + 3);
+      const KF kn = read_k(i + 1);                       // past the last tile: stale ring data, result unused
+      const VF vf = read_v(i);
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x16 s_next = qk(kn);
+      float psum = 0.f;
+      half8 pf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(s[r] - m_ref);
+        psum += pv;
+        pf[r >> 3][r & 7] = (half_t)pv;
+      }
+      psum += __shfl_xor(psum, 32, 64);
+      l_run += psum;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) o[t] = mfma32(vf.f[2 * t], pf[0], o[t]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) o[t] = mfma32(vf.f[2 * t + 1], pf[1], o[t]);
+      s = s_next;
+      tmax = rowmax(s);
+      ++i;
+      if (i >= n) { done = true; break; }
+      if (__any(tmax > m_ref + RESCALE_THR)) break;
+    }
+    if (done) break;
+  }
+
+  const float inv = 1.f / l_run;
+  half_t* orow = p.o + qrow * p.ldo + head * HD;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = t * 32 + 8 * g + 4 * fh;
+      if (d < HD) {
+        const half4 h = {(half_t)(o[t][4 * g] * inv), (half_t)(o[t][4 * g + 1] * inv),
+                         (half_t)(o[t][4 * g + 2] * inv), (half_t)(o[t][4 * g + 3] * inv)};
+        *reinterpret_cast<half4*>(orow + d) = h;
+      }
+    }
+  }
+}
 }  // namespace
 
 hipError_t hiera_attn_launch(const HieraAttnParams& p, hipStream_t stream) {
@@ -189,7 +393,10 @@ hipError_t hiera_attn_launch(const HieraAttnParams& p, hipStream_t stream) {
   const int total = p.num_groups * p.heads * qtiles;
   const int blocks = (total + 3) / 4;
   const bool mask = !(p.wq >= p.GQ && p.wk >= p.GK);
-  if (qtiles % 4 == 0) {
+  static const bool use_v1 = getenv("SAM2MI_HATTN_V1") != nullptr;     // A/B switch: the register-staged kernel
+  if (qtiles % 4 == 0 && !mask && !use_v1 && (p.ldvT & 7) == 0) {
+    hiera_attn_v2_kernel<<<dim3(total / 4), dim3(256), 0, stream>>>(p);
+  } else if (qtiles % 4 == 0) {
     if (mask) hiera_attn_kernel<true, true><<<dim3(blocks), dim3(256), 0, stream>>>(p);
     else hiera_attn_kernel<true, false><<<dim3(blocks), dim3(256), 0, stream>>>(p);
   } else {
