@@ -97,6 +97,10 @@ int sam2mi_dense_pe(sam2mi_ctx* ctx, void* stream, float* out);
 
 /* Encode B frames (B <= max_batch) and keep their features in feature-cache slots feat_slot[i]. */
 int sam2mi_video_encode(sam2mi_ctx* ctx, void* stream, const float* frames, int B, const int32_t* feat_slots);
+/* Same from DECODED frames: frames_hwc uint8 [B, image_size, image_size, 3] (device memory).  The /255, -mean, /std of
+ * load_video_frames (utils/misc.py:270-276) is applied in f32 inside the patch-embedding gather, so the result is
+ * bit-identical to sam2mi_video_encode on the normalised f32 frames and the 12.6 MB f32 frame is never materialised. */
+int sam2mi_video_encode_u8(sam2mi_ctx* ctx, void* stream, const uint8_t* frames_hwc, int B, const int32_t* feat_slots);
 
 /* Which memories / object pointers a tracked frame attends to (SAM2Base._prepare_memory_conditioned_features). */
 typedef struct sam2mi_mem_select {
@@ -124,6 +128,16 @@ typedef struct sam2mi_frame_out {
  * SAM heads on feat + no_mem_embed; stores obj_ptr / score / low-res mask in bank slot `bank_slot`. */
 int sam2mi_video_click(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int Np,
                        int multimask, int bank_slot, const sam2mi_frame_out* out);
+
+/* Hole filling (fill_holes_in_mask_scores, utils/misc.py:312-338; replaces the reference's CUDA extension
+ * csrc/connected_components.cu:62-282, bound at utils/misc.py:59-62): background (score <= 0) 8-connected components
+ * of at most max_area pixels get score 0.1.  masks_in / masks_out: [N, H, W] f32 device buffers, must not alias;
+ * 1 <= max_area <= 63. */
+int sam2mi_fill_holes(sam2mi_ctx* ctx, void* stream, const float* masks_in, float* masks_out, int N, int H, int W, int max_area);
+/* Apply it inside the fused video path to every stored low-res mask (SAM2Base.fill_hole_area, build_sam.py:129;
+ * applied where sam2_video_predictor_official.py:889-894 does: after the frame's own memory encoding on tracked
+ * frames, before it on prompted frames).  0 (default) = off. */
+int sam2mi_set_fill_hole_area(sam2mi_ctx* ctx, int max_area);
 
 /* Memory encoder for a bank slot (propagate_in_video_preflight / _encode_new_memory): uses the low-res
  * mask and object score stored in the slot, writes the bf16-rounded memory features into the slot. */

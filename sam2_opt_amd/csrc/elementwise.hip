@@ -128,7 +128,13 @@ __global__ void cast_add_kernel(const float* __restrict__ a, int lda, const floa
 
 // ------------------------------------------------------------------ patch-embed im2col
 // one thread = one (token, 8-wide k chunk); 20 chunks per token (K padded 147 -> 160)
-__global__ void im2col_patch_kernel(const float* __restrict__ img, int B, int S, half_t* __restrict__ A) {
+// U8: img is uint8 [B, S, S, 3] (decoded HWC frames); the /255, -mean, /std of load_video_frames (utils/misc.py:270-276)
+// is applied here in f32, in that order, so the f16 operand is bit-identical to the one built from a normalised f32 frame
+template <bool U8>
+__global__ void im2col_patch_kernel(const void* __restrict__ img_, int B, int S, half_t* __restrict__ A) {
+  const float* img = static_cast<const float*>(img_);
+  const uint8_t* img8 = static_cast<const uint8_t*>(img_);
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
   const int G = S / 4;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)B * G * G * 20;
@@ -149,7 +155,10 @@ __global__ void im2col_patch_kernel(const float* __restrict__ img, int B, int S,
     if (k < 147) {
       const int c = k / 49, r = k % 49, ky = r / 7, kx = r % 7;
       const int iy = y * 4 - 3 + ky, ix = x * 4 - 3 + kx;
-      if (iy >= 0 && iy < S && ix >= 0 && ix < S) v = img[(((size_t)b * 3 + c) * S + iy) * S + ix];
+      if (iy >= 0 && iy < S && ix >= 0 && ix < S) {
+        if (U8) v = ((float)img8[(((size_t)b * S + iy) * S + ix) * 3 + c] / 255.0f - mean[c]) / stdv[c];
+        else v = img[(((size_t)b * 3 + c) * S + iy) * S + ix];
+      }
     }
     out[j] = (half_t)v;
   }
@@ -273,7 +282,12 @@ hipError_t cast_add_launch(const float* a, int lda, const float* b, int ldb, int
 }
 hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStream_t s) {
   const size_t total = (size_t)B * (S / 4) * (S / 4) * 20;
-  im2col_patch_kernel<<<grid1d(total), dim3(256), 0, s>>>(img, B, S, A);
+  im2col_patch_kernel<false><<<grid1d(total), dim3(256), 0, s>>>(img, B, S, A);
+  return hipGetLastError();
+}
+hipError_t im2col_patch_u8_launch(const uint8_t* img_hwc, int B, int S, half_t* A, hipStream_t s) {
+  const size_t total = (size_t)B * (S / 4) * (S / 4) * 20;
+  im2col_patch_kernel<true><<<grid1d(total), dim3(256), 0, s>>>(img_hwc, B, S, A);
   return hipGetLastError();
 }
 hipError_t pool_tokens_f32_launch(const float* in, int ldin, float* out, int ldout, int nwin, int w, int C, hipStream_t s) {

@@ -147,6 +147,8 @@ struct sam2mi_ctx {
   float* d_tokens_in = nullptr; float* d_sparse = nullptr;
   half_t* d_up1_16 = nullptr; half_t* d_up2_16 = nullptr; float* d_g = nullptr;
   float* d_hyper = nullptr; half_t* d_hyper16 = nullptr;
+  float* d_fill_tmp = nullptr;     // [65536] hole-filling scratch
+  int fill_hole_area = 0;          // sam2mi_set_fill_hole_area: 0 = off (SAM2Base.fill_hole_area, build_sam.py:129)
   float* d_masks = nullptr; float* d_iou = nullptr; float* d_obj = nullptr; float* d_mtok = nullptr;
   float* d_low_multi = nullptr; float* d_low_sel = nullptr; float* d_tok_sel = nullptr; int* d_best = nullptr; float* d_iou_sel = nullptr;
   float* d_ptr = nullptr; float* d_pts = nullptr; int* d_labels = nullptr;
@@ -189,7 +191,8 @@ GemmParams lin_params(const half_t* A, int lda, int M, const Lin16& L);         
 
 // engine_encoder.hip
 struct EncOut { float* feat2; float* fpn1; float* fpn0; };   // token-major [B, HW, C]
-int encoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, const EncOut* outs /*[B]*/);
+// img: normalised f32 NCHW, or (img == nullptr) img_u8: decoded uint8 HWC frames normalised on the fly
+int encoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, const EncOut* outs /*[B]*/, const uint8_t* img_u8 = nullptr);
 int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& blk, int B, int& H, int& W, int& wcur);
 
 // engine_track.hip

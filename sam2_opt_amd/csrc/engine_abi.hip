@@ -177,8 +177,40 @@ extern "C" int sam2mi_video_encode(sam2mi_ctx* ctx, void* stream, const float* f
   return encoder_forward(ctx, S(stream), frames, B, outs.data());
 }
 
+extern "C" int sam2mi_set_fill_hole_area(sam2mi_ctx* ctx, int max_area) {
+  if (!ctx) return 1;
+  if (max_area < 0 || max_area > FILL_HOLES_MAX_AREA) return sam2mi_set_error(ctx, __func__, "fill_hole_area out of range (0..63)");
+  ctx->fill_hole_area = max_area;
+  return 0;
+}
+
+extern "C" int sam2mi_fill_holes(sam2mi_ctx* ctx, void* stream, const float* masks_in, float* masks_out, int N, int H, int W, int max_area) {
+  if (!ctx) return 1;
+  if (!masks_in || !masks_out || masks_in == masks_out) return sam2mi_set_error(ctx, __func__, "in / out must be distinct non-null buffers");
+  if (max_area < 1 || max_area > FILL_HOLES_MAX_AREA) return sam2mi_set_error(ctx, __func__, "max_area out of range (1..63)");
+  if (N <= 0 || H <= 0 || W <= 0 || (long)H * W > (1L << 30)) return sam2mi_set_error(ctx, __func__, "bad mask shape");
+  CHK(fill_holes_launch(masks_in, masks_out, N, H, W, max_area, S(stream)));
+  return 0;
+}
+
+extern "C" int sam2mi_video_encode_u8(sam2mi_ctx* ctx, void* stream, const uint8_t* frames_hwc, int B, const int32_t* feat_slots) {
+  REQUIRE_READY();
+  if (!frames_hwc) return sam2mi_set_error(ctx, __func__, "null frames");
+  std::vector<EncOut> outs(B);
+  for (int b = 0; b < B; ++b) {
+    const int sl = feat_slots[b];
+    if (sl < 0 || sl >= (int)ctx->feats.size()) return sam2mi_set_error(ctx, __func__, "feature slot out of range");
+    outs[b] = {ctx->feats[sl].feat2, ctx->feats[sl].fpn1, ctx->feats[sl].fpn0};
+  }
+  return encoder_forward(ctx, S(stream), nullptr, B, outs.data(), frames_hwc);
+}
+
 // SAM heads after the decoder: select, obj_ptr; writes bank slot + optional outputs
-static int sam_heads_finish(sam2mi_ctx* ctx, hipStream_t s, int multimask, int bank_slot, const sam2mi_frame_out* out) {
+// `fill_before_outputs`: hole filling of the stored low-res mask (fill_holes_in_mask_scores on pred_masks,
+// sam2_video_predictor_official.py:889-894) happens here; a tracked frame passes `mem_feat_slot >= 0` to run its
+// memory encoder on the UNFILLED mask first, as track_step does (sam2_base_official.py:1151-1166 precedes :889).
+static int sam_heads_finish(sam2mi_ctx* ctx, hipStream_t s, int multimask, int bank_slot, const sam2mi_frame_out* out,
+                            int mem_feat_slot = -1) {
   sam2mi_ctx::BankSlot& bk = ctx->bank[bank_slot];
   CHK(select_mask_launch(ctx->d_masks, ctx->d_iou, ctx->d_obj, ctx->d_mtok, multimask, ctx->d_best + 2, 0.05f, 0.98f,
                          ctx->d_low_multi, bk.low_mask, ctx->d_tok_sel, ctx->d_best, ctx->d_iou_sel, s));
@@ -193,6 +225,11 @@ static int sam_heads_finish(sam2mi_ctx* ctx, hipStream_t s, int multimask, int b
   }
   CHK(gate_obj_ptr_launch(bk.obj_ptr, ctx->no_obj_ptr, ctx->d_obj, 256, s));
   CHK(hipMemcpyAsync(bk.obj_score, ctx->d_obj, sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (mem_feat_slot >= 0) CHKI(sam2mi_video_encode_memory(ctx, (void*)s, mem_feat_slot, bank_slot, 0));
+  if (ctx->fill_hole_area > 0) {
+    CHK(fill_holes_launch(bk.low_mask, ctx->d_fill_tmp, 1, 256, 256, ctx->fill_hole_area, s));
+    CHK(hipMemcpyAsync(bk.low_mask, ctx->d_fill_tmp, 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
   if (out) {
     const int nm = multimask ? 3 : 1;
     if (out->low_res_masks) CHK(hipMemcpyAsync(out->low_res_masks, bk.low_mask, 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -323,7 +360,6 @@ extern "C" int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, 
   CHK(hipMemcpyAsync(ctx->d_sparse + (size_t)T * 256, ctx->d_sparse + (size_t)(T - 1) * 256, 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
   T += 1;
   CHKI(decoder_forward(ctx, s, ctx->t_pix, ctx->no_mask_embed, 1, ctx->dense_pe, ctx->d_sparse, T, f.fpn0, f.fpn1));
-  CHKI(sam_heads_finish(ctx, s, 1, bank_slot, out));
-  if (run_mem_encoder) CHKI(sam2mi_video_encode_memory(ctx, stream, feat_slot, bank_slot, 0));
+  CHKI(sam_heads_finish(ctx, s, 1, bank_slot, out, run_mem_encoder ? feat_slot : -1));
   return 0;
 }

@@ -626,6 +626,7 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ALLOC(ctx->t_kall16, half_t, (size_t)NKCAP * 1024);
   ALLOC(ctx->t_vTall16, half_t, (size_t)1024 * NKCAP);
   ALLOC(ctx->t_opart, float, (size_t)16 * 4096 * 256);
+  ALLOC(ctx->d_fill_tmp, float, (size_t)65536);
   ALLOC(ctx->t_ml, float, (size_t)16 * 4096 * 2);
   ALLOC(ctx->t_ptr_tok, float, 128 * 64);
   ALLOC(ctx->t_ptr_pos, float, 128 * 64);

@@ -87,12 +87,13 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
 
 // Runs patch embedding + all blocks; fills ctx->ws_lat[0..3] (neck laterals, window-major) and returns
 // the window size of each level's token order in wlev[].
-static int trunk_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, int wlev[4]) {
+static int trunk_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, const uint8_t* img_u8, int B, int wlev[4]) {
   const sam2mi_config& c = ctx->cfg;
   const int G = c.image_size / 4, E = c.embed_dim;
   int H = G, W = G, wcur = 8;
   // patch embed (conv 7x7 s4 p3 as im2col GEMM) + position table, written in window-major order
-  CHK(im2col_patch_launch(img, B, c.image_size, ctx->ws_a16, s));
+  if (img_u8) CHK(im2col_patch_u8_launch(img_u8, B, c.image_size, ctx->ws_a16, s));
+  else CHK(im2col_patch_launch(img, B, c.image_size, ctx->ws_a16, s));
   {
     GemmParams p = lin_params(ctx->ws_a16, 160, B * G * G, ctx->patch);
     p.res = ctx->pos_tab; p.ldres = E; p.res_mod = G * G;
@@ -126,13 +127,14 @@ static int trunk_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B
   return level == 4 ? 0 : sam2mi_set_error(ctx, "trunk_forward", "expected 4 stage outputs");
 }
 
-int encoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, const EncOut* outs) {
+int encoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, const EncOut* outs, const uint8_t* img_u8) {
   const sam2mi_config& c = ctx->cfg;
   if (!ctx->finalized) return sam2mi_set_error(ctx, "encoder_forward", "weights not finalized");
   if (B <= 0 || B > c.max_batch) return sam2mi_set_error(ctx, "encoder_forward", "batch exceeds cfg.max_batch");
   const int G = c.image_size / 4;
   int wlev[4];
-  CHKI(trunk_forward(ctx, s, img, B, wlev));
+  if (!img && !img_u8) return sam2mi_set_error(ctx, "encoder_forward", "no input frames");
+  CHKI(trunk_forward(ctx, s, img, img_u8, B, wlev));
   // level 2 (64x64): lateral + nearest-2x of level 3, to row-major tokens  (fpn_top_down_levels [2,3], scalp 1)
   {
     float* dst = ctx->ws_x;   // staging [B, 4096, 256]

@@ -13,6 +13,8 @@ hipError_t cast_add_launch(const float* a, int lda, const float* b, int ldb, int
 // patch-embed im2col: img [B,3,S,S] f32 -> A [B*(S/4)^2, 160] f16, rows in window-major (w=8) token order,
 // column k = c*49 + ky*7 + kx (conv 7x7, stride 4, pad 3); columns 147..159 are zero.
 hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStream_t s);
+// same from decoded frames: uint8 [B, S, S, 3] HWC, normalised ((v/255 - mean)/std, ImageNet constants) on the fly
+hipError_t im2col_patch_u8_launch(const uint8_t* img_hwc, int B, int S, half_t* A, hipStream_t s);
 // 2x2 max-pool inside w x w windows of window-major tokens: in [nwin*w*w, C] -> out [nwin*(w/2)^2, C]
 hipError_t pool_tokens_f32_launch(const float* in, int ldin, float* out, int ldout, int nwin, int w, int C, hipStream_t s);
 hipError_t pool_tokens_f16_launch(const half_t* in, int ldin, half_t* out, int ldout, int nwin, int w, int C, hipStream_t s);
@@ -39,6 +41,12 @@ hipError_t conv3x3s2_ln_gelu_launch(const float* in, int Hin, int CIN, int COUT,
 hipError_t im2col3x3s2_launch(const half_t* in, int Hin, int CIN, half_t* A, hipStream_t s);
 // depth-wise 7x7 pad 3 on NHWC f32 [H*H, C]; w [C, 49]
 hipError_t dwconv7_launch(const float* in, int H, int C, const float* w, const float* b, float* out, hipStream_t s);
+
+// ---------------------------------------------------------------- postproc.hip
+// fill_holes_in_mask_scores (utils/misc.py:312-338): background (score <= 0) 8-connected components of at most max_area
+// pixels get score 0.1.  in / out: [N, H, W] f32, must not alias; 1 <= max_area <= FILL_HOLES_MAX_AREA.
+constexpr int FILL_HOLES_MAX_AREA = 63;      // visited list of max_area + 1 ints per thread in LDS (64 KiB per workgroup)
+hipError_t fill_holes_launch(const float* in, float* out, int N, int H, int W, int max_area, hipStream_t s);
 
 // ---------------------------------------------------------------- heads.hip (prompt encoder, mask decoder glue)
 // y[t, n] = act(sum_k x[t, k] W[n, k] + b[n]) (+ res[t, n]);  f32 everywhere, T <= 64.  act: 0 none, 2 relu, 3 sigmoid

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libsam2mi.so")
 EXPORTS = [
     "sam2mi_abi_version", "sam2mi_create", "sam2mi_destroy", "sam2mi_last_error", "sam2mi_load_weight",
     "sam2mi_finalize_weights", "sam2mi_image_encoder", "sam2mi_set_image_e2e", "sam2mi_memory_attention",
-    "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_dense_pe", "sam2mi_video_encode",
+    "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_dense_pe", "sam2mi_video_encode", "sam2mi_video_encode_u8", "sam2mi_fill_holes", "sam2mi_set_fill_hole_area",
     "sam2mi_video_click", "sam2mi_image_predict", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_resize_bilinear",
     "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
     "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench",
@@ -214,6 +214,29 @@ class Engine:
         B = frames.shape[0]
         sl = (C.c_int32 * B)(*feat_slots)
         self._check(self.lib.sam2mi_video_encode(self.h, self.stream, _ptr(frames), B, sl), "sam2mi_video_encode")
+
+    def video_encode_u8(self, frames_hwc: torch.Tensor, feat_slots: Sequence[int]):
+        """frames_hwc: uint8 (B, S, S, 3) decoded frames on the engine's device; normalised inside the patch-embed gather."""
+        if frames_hwc.dtype != torch.uint8 or not frames_hwc.is_contiguous() or frames_hwc.device != self.device:
+            raise ValueError("video_encode_u8 wants a contiguous uint8 (B,S,S,3) tensor on the engine's device")
+        S = self.cfg["image_size"]
+        if tuple(frames_hwc.shape[1:]) != (S, S, 3):
+            raise ValueError(f"video_encode_u8 wants (B,{S},{S},3) frames, got {tuple(frames_hwc.shape)}")
+        B = frames_hwc.shape[0]
+        sl = (C.c_int32 * B)(*feat_slots)
+        self._check(self.lib.sam2mi_video_encode_u8(self.h, self.stream, _ptr(frames_hwc), B, sl), "sam2mi_video_encode_u8")
+
+    def set_fill_hole_area(self, max_area: int):
+        self._check(self.lib.sam2mi_set_fill_hole_area(self.h, int(max_area)), "sam2mi_set_fill_hole_area")
+
+    def fill_holes(self, masks: torch.Tensor, max_area: int) -> torch.Tensor:
+        """masks: float32 (..., H, W) on the engine's device -> new tensor, small background holes set to 0.1."""
+        _chk_f32(masks)
+        H, W = masks.shape[-2:]
+        out = torch.empty_like(masks)
+        self._check(self.lib.sam2mi_fill_holes(self.h, self.stream, _ptr(masks), _ptr(out), masks.numel() // (H * W), H, W, int(max_area)),
+                    "sam2mi_fill_holes")
+        return out
 
     def _frame_out(self, want: dict) -> FrameOut:
         fo = FrameOut()

@@ -11,8 +11,8 @@ resident in HBM, the host only passes slot indices - there is no per-frame host<
 Differences from the reference, all deliberate:
   * the image encoder runs on batches of upcoming frames (`encode_batch`), since it does not depend on
     the tracking state; the reference encodes one frame at a time;
-  * `fill_hole_area` defaults to 0: the reference's hole filling needs its CUDA extension and is silently
-    skipped without it (utils/misc.py:321-336);
+  * `fill_hole_area` defaults to 0 (the goldens were recorded from the reference without its CUDA extension, where the
+    step is silently skipped, utils/misc.py:321-336); pass 8 (build_sam.py:129) to fill holes on the device;
   * mask prompts (`add_new_mask`) and correction clicks on already-tracked frames are not implemented yet.
 """
 from __future__ import annotations
@@ -46,8 +46,7 @@ class SAM2VideoPredictor:
         self.max_obj_ptrs_in_encoder = self.cfg["max_obj_ptrs_in_encoder"]
         self.fill_hole_area = fill_hole_area
         self.non_overlap_masks = non_overlap_masks
-        if fill_hole_area > 0:
-            raise NotImplementedError("connected-component hole filling is not implemented on this backend yet")
+        self.engine.set_fill_hole_area(fill_hole_area)       # 0 = off; > 0: holes filled on the device (postproc.hip)
         self.backend = "hip"
         self.debug_trace = None      # set to {} to record per-frame intermediates (parity tests)
 
@@ -64,11 +63,17 @@ class SAM2VideoPredictor:
     # ------------------------------------------------------------------ state
     @torch.inference_mode()
     def init_state(self, video_path=None, frames: Optional[torch.Tensor] = None, video_height: Optional[int] = None,
-                   video_width: Optional[int] = None, offload_video_to_cpu: bool = False, **_unused):
+                   video_width: Optional[int] = None, offload_video_to_cpu: bool = False, frames_u8=None, **_unused):
         """`frames`: float32 (T,3,1024,1024) already /255 and mean/std normalised (what load_video_frames returns),
-        on CPU or GPU; or `video_path`: a folder of JPEGs (needs PIL)."""
+        on CPU or GPU; or `frames_u8`: decoded uint8 (T,1024,1024,3) frames (numpy or torch) - normalised on the device
+        inside the patch-embedding gather, bit-identical to the float path at a quarter of the bytes; or `video_path`: a
+        folder of JPEGs (needs PIL; decoded + resized on the host like utils/misc.py:92-101, then the uint8 path)."""
+        if frames is None and frames_u8 is None:
+            frames_u8, video_height, video_width = _load_jpeg_folder(video_path, self.cfg)
         if frames is None:
-            frames, video_height, video_width = _load_jpeg_folder(video_path, self.cfg)
+            frames = torch.from_numpy(frames_u8) if isinstance(frames_u8, np.ndarray) else frames_u8
+            if frames.dtype != torch.uint8 or frames.dim() != 4 or tuple(frames.shape[1:]) != (self.image_size, self.image_size, 3):
+                raise ValueError(f"frames_u8 must be uint8 (T,{self.image_size},{self.image_size},3)")
         if not offload_video_to_cpu:
             frames = frames.to(self.device)
         st = {
@@ -133,8 +138,10 @@ class SAM2VideoPredictor:
             st["free_feat_slots"].append(sl)
         slots = [st["free_feat_slots"].pop() for _ in idxs]
         imgs = st["images"][idxs] if len(idxs) > 1 else st["images"][idxs[0]:idxs[0] + 1]
-        imgs = imgs.to(self.device, dtype=torch.float32).contiguous()
-        self.engine.video_encode(imgs, slots)
+        if imgs.dtype == torch.uint8:                         # decoded HWC frames: normalised inside the engine
+            self.engine.video_encode_u8(imgs.to(self.device).contiguous(), slots)
+        else:
+            self.engine.video_encode(imgs.to(self.device, dtype=torch.float32).contiguous(), slots)
         for t, sl in zip(idxs, slots):
             m[t] = sl
         return m[frame_idx]
@@ -329,4 +336,4 @@ def _load_jpeg_folder(path, cfg):
         im = Image.open(os.path.join(path, n))
         W, H = im.size
         frames[i] = np.array(im.convert("RGB").resize((S, S)))
-    return normalize_frames(frames, cfg), H, W
+    return frames, H, W

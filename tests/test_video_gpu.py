@@ -78,3 +78,19 @@ def test_video_intermediates_match_oracle(predictor, sd_large, cfg_large):
             assert int(dbg["best_idx"].item()) == int(torch.argmax(tr["ious"], dim=-1).item())
     finally:
         predictor.debug_trace = None
+
+
+def test_uint8_frames_bit_identical_to_float_frames(predictor, cfg_large):
+    """Frame ingest: decoded uint8 HWC frames normalised inside the patch-embed gather give exactly the
+    masks of the float path (same f32 arithmetic, same order as utils/misc.py:270-276)."""
+    from sam2_opt_amd.synthetic import normalize_frames, synthetic_frames_u8
+    u8 = synthetic_frames_u8(seed=5, num_frames=6)
+    outs = []
+    for kw in (dict(frames=normalize_frames(u8, cfg_large)), dict(frames_u8=u8)):
+        st = predictor.init_state(video_height=1024, video_width=1024, **kw)
+        predictor.add_new_points_or_box(st, 0, 1, points=np.array([CLICK], np.float32), labels=np.array([1], np.int32))
+        outs.append([vm.clone() for _, _, vm in predictor.propagate_in_video(st)])
+        predictor.reset_state(st)
+    assert len(outs[0]) == len(outs[1]) == 6
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
