@@ -30,7 +30,8 @@ from .synthetic import normalize_frames
 
 class SAM2VideoPredictor:
     def __init__(self, model: str = "large", state_dict=None, ckpt_path: Optional[str] = None, device=None,
-                 encode_batch: int = 8, bank_slots: int = 96, fill_hole_area: int = 0, non_overlap_masks: bool = False):
+                 encode_batch: int = 8, bank_slots: int = 96, fill_hole_area: int = 0, non_overlap_masks: bool = False,
+                 overlap_encode: bool = True):
         self.cfg = get_config(model)
         if state_dict is None and ckpt_path is not None:
             # same contract as build_sam._load_checkpoint (build_sam.py:164-174)
@@ -47,6 +48,11 @@ class SAM2VideoPredictor:
         self.fill_hole_area = fill_hole_area
         self.non_overlap_masks = non_overlap_masks
         self.engine.set_fill_hole_area(fill_hole_area)       # 0 = off; > 0: holes filled on the device (postproc.hip)
+        # The image encoder of the NEXT batch of frames runs on its own HIP stream beside the tracking of the current
+        # batch: the tracking path is a chain of small latency-bound kernels (M = 4096 GEMMs, 8-token decoder ops) that
+        # leaves most CUs idle, the encoder fills them.  The two paths share no workspace inside the engine.
+        self.overlap_encode = bool(overlap_encode)
+        self._enc_stream = torch.cuda.Stream(device=self.device) if self.overlap_encode else None
         self.backend = "hip"
         self.debug_trace = None      # set to {} to record per-frame intermediates (parity tests)
 
@@ -84,6 +90,7 @@ class SAM2VideoPredictor:
             "output_dict_per_obj": {}, "temp_output_dict_per_obj": {}, "frames_tracked_per_obj": {},
             "feat_slot_of_frame": OrderedDict(), "free_feat_slots": list(range(self.engine.feat_slots)),
             "free_bank_slots": list(range(self.engine.bank_slots)),
+            "feat_events": {},          # frame -> event recorded on the encoder stream (features still in flight)
         }
         self._ensure_features(st, 0, forward=True)       # warm up the backbone like the reference (:204)
         return st
@@ -124,26 +131,57 @@ class SAM2VideoPredictor:
             st["free_bank_slots"].append(out["slot"])
             out["slot"] = None
 
-    def _ensure_features(self, st, frame_idx: int, forward: bool = True) -> int:
-        """Feature-cache slot of `frame_idx`; on a miss encode a batch of frames starting there
-        (cf. _get_image_feature :810-841, which caches exactly one frame)."""
+    def _encode_batch(self, st, start: int, forward: bool, side: bool):
+        """Encode up to `encode_batch` uncached frames from `start` in the tracking direction into feature-cache slots."""
         m = st["feat_slot_of_frame"]
-        if frame_idx in m:
-            return m[frame_idx]
         T = st["num_frames"]
         step = 1 if forward else -1
-        idxs = [t for t in range(frame_idx, frame_idx + step * self.encode_batch, step) if 0 <= t < T and t not in m]
+        idxs = [t for t in range(start, start + step * self.encode_batch, step) if 0 <= t < T and t not in m]
+        if not idxs:
+            return
         while len(st["free_feat_slots"]) < len(idxs):          # evict the oldest cached frames
-            _, sl = m.popitem(last=False)
+            t_old, sl = m.popitem(last=False)
+            st["feat_events"].pop(t_old, None)
             st["free_feat_slots"].append(sl)
         slots = [st["free_feat_slots"].pop() for _ in idxs]
-        imgs = st["images"][idxs] if len(idxs) > 1 else st["images"][idxs[0]:idxs[0] + 1]
-        if imgs.dtype == torch.uint8:                         # decoded HWC frames: normalised inside the engine
-            self.engine.video_encode_u8(imgs.to(self.device).contiguous(), slots)
+
+        def run():
+            imgs = st["images"][idxs] if len(idxs) > 1 else st["images"][idxs[0]:idxs[0] + 1]
+            if imgs.dtype == torch.uint8:                         # decoded HWC frames: normalised inside the engine
+                self.engine.video_encode_u8(imgs.to(self.device).contiguous(), slots)
+            else:
+                self.engine.video_encode(imgs.to(self.device, dtype=torch.float32).contiguous(), slots)
+        if side:
+            main = torch.cuda.current_stream(self.device)
+            self._enc_stream.wait_stream(main)                   # the evicted slots were read by work already queued on `main`
+            with torch.cuda.stream(self._enc_stream):
+                run()
+                ev = torch.cuda.Event()
+                ev.record(self._enc_stream)
+            for t in idxs:
+                st["feat_events"][t] = ev
         else:
-            self.engine.video_encode(imgs.to(self.device, dtype=torch.float32).contiguous(), slots)
+            run()
         for t, sl in zip(idxs, slots):
             m[t] = sl
+
+    def _ensure_features(self, st, frame_idx: int, forward: bool = True) -> int:
+        """Feature-cache slot of `frame_idx`; on a miss encode a batch of frames starting there
+        (cf. _get_image_feature :810-841, which caches exactly one frame).  With `overlap_encode` the batch AFTER the one
+        in use is encoded ahead of time on the encoder stream."""
+        m = st["feat_slot_of_frame"]
+        if frame_idx not in m:
+            self._encode_batch(st, frame_idx, forward, side=False)
+        ev = st["feat_events"].pop(frame_idx, None)
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        if self.overlap_encode:
+            step = 1 if forward else -1
+            t = frame_idx + step
+            while t in m and abs(t - frame_idx) <= self.encode_batch:
+                t += step
+            if 0 <= t < st["num_frames"] and abs(t - frame_idx) <= self.encode_batch:
+                self._encode_batch(st, t, forward, side=True)
         return m[frame_idx]
 
     # ------------------------------------------------------------------ prompts
@@ -204,10 +242,14 @@ class SAM2VideoPredictor:
         return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
 
     def _video_res(self, st, low):
+        """_get_orig_video_res_output (sam2_video_predictor_official.py:489-509)."""
         H, W = st["video_height"], st["video_width"]
-        if low.shape[-2:] == (H, W):
-            return low
-        return self.engine.resize_bilinear(low, (H, W))
+        vid = low if low.shape[-2:] == (H, W) else self.engine.resize_bilinear(low, (H, W))
+        if self.non_overlap_masks and vid.shape[0] > 1:
+            # SAM2Base._apply_non_overlapping_constraints (sam2_base_official.py:1191-1209): keep the best object per pixel
+            keep = torch.argmax(vid, dim=0, keepdim=True) == torch.arange(vid.shape[0], device=vid.device)[:, None, None, None]
+            vid = torch.where(keep, vid, torch.clamp(vid, max=-10.0))
+        return vid
 
     # ------------------------------------------------------------------ propagation
     @torch.inference_mode()

@@ -94,3 +94,24 @@ def test_uint8_frames_bit_identical_to_float_frames(predictor, cfg_large):
     assert len(outs[0]) == len(outs[1]) == 6
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_two_objects_are_tracked_independently(predictor):
+    """Multi-object clips (the reference loops objects with B = 1 over shared frame features,
+    sam2_video_predictor_official.py:691-725): each object's masks equal those of a single-object run."""
+    from sam2_opt_amd.synthetic import synthetic_frames_u8
+    u8 = synthetic_frames_u8(seed=7, num_frames=5)
+    clicks = {1: (512.0, 512.0), 2: (300.0, 700.0)}
+
+    def run(obj_ids):
+        st = predictor.init_state(frames_u8=u8, video_height=1024, video_width=1024)
+        for oid in obj_ids:
+            predictor.add_new_points_or_box(st, 0, oid, points=np.array([clicks[oid]], np.float32), labels=np.array([1], np.int32))
+        out = [(ids, vm.clone()) for _, ids, vm in predictor.propagate_in_video(st)]
+        predictor.reset_state(st)
+        return out
+    both, one, two = run([1, 2]), run([1]), run([2])
+    assert len(both) == 5
+    for (ids, vm), (_, a), (_, b) in zip(both, one, two):
+        assert list(ids) == [1, 2] and vm.shape[0] == 2
+        assert torch.equal(vm[0:1], a) and torch.equal(vm[1:2], b)
