@@ -25,7 +25,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 template <int BM, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(WM * WN * 64, (STAGES > 2 && WM * WN == 8) ? 2 : 2) void gemm_v2_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_v2_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -301,7 +301,9 @@ static inline long tiles_of(const GemmParams& p, int bm, int bn) { return (long)
 // structure at 2-3 workgroups per CU: its main loop tops out near 900 TFLOP/s even on cache-resident operands, and with
 // K <= 4608 the un-overlapped prologue / epilogue of every output tile costs another 20-25 %.  What helps is waves:
 // 8-wave workgroups beat 4-wave ones on every large shape; 128x128 (2 per CU) wins when N pads to 128 with <= 8 % waste,
-// 128x64 (3 per CU) otherwise; 256x128 and 3/4-stage rings (1 workgroup per CU) lose 30-50 %.
+// 128x64 (3 per CU) otherwise; 256x128 and 3/4-stage rings (1 workgroup per CU) lose 30-50 %, 16-wave 256x128 3-stage
+// workgroups lose 10 %, a 256x256 8-wave tile on this loop structure loses 50 % (it needs the fine-grained multi-phase
+// schedule, not more bytes per barrier).  The loop is bound by the per-CU L2->LDS rate (~25-29 B/clk) at these tiles.
 hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   const int force = p.tile_hint;
   if (force == 6) return gemm_v3_launch(p, s);
@@ -318,7 +320,8 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   if (force == 5) return v2_launch<64, 64, 2, 2, 2>(p, s);
   if (tiles_of(p, 128, 64) >= 2048) {
     const int n128 = ((p.N + 127) / 128) * 128;
-    if (tiles_of(p, 128, 128) >= 1536 && (n128 - p.N) * 100 <= 8 * p.N) return v2_launch<128, 128, 4, 2, 2>(p, s);
+    const long t128 = tiles_of(p, 128, 128);
+    if ((t128 >= 1536 || (t128 >= 512 && p.K >= 2048)) && (n128 - p.N) * 100 <= 8 * p.N) return v2_launch<128, 128, 4, 2, 2>(p, s);
     return v2_launch<128, 64, 4, 2, 2>(p, s);
   }
   return v2_launch<64, 64, 2, 2, 2>(p, s);
