@@ -220,10 +220,13 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
     const int vrow = vp * 16 + (lane >> 2), vpc = lane & 3;
     v_src[j] = vrow * p.ldvT + ((vpc ^ ((vrow >> 2) & 3)) << 3);
   }
-  auto issue = [&](int i) {                            // tile t_lo + i -> ring stage i % NST
+  // tile t_lo + min(i, n-1) -> ring stage i % NST.  Past the last tile the last one is simply loaded again (into a free
+  // stage, never read): every iteration then issues exactly 8 pieces per wave and the loop needs no branch around the DMA.
+  auto issue = [&](int i) {
     char* sb = smem + (i % NST) * STAGE3_B;
-    const half_t* kb = p.k + (size_t)(t_lo + i) * 32 * p.ldk;
-    const half_t* vb = p.vT + (t_lo + i) * 32;
+    const int tile = t_lo + min(i, n - 1);
+    const half_t* kb = p.k + (size_t)tile * 32 * p.ldk;
+    const half_t* vb = p.vT + tile * 32;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + k_src[j]), (lds_ptr_t)(sb + (wave * 4 + j) * K3_PIECE), 16, 0, 0);
@@ -255,23 +258,21 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
     }
     return v;
   };
-  // two independent MFMA chains over d (zero start); keys past Nk are masked when the chains are summed
-  auto qk_init = [&](f32x16& sa, f32x16& sb) {
+  // one MFMA chain over d (a single accumulation chain of this instruction issues at full rate); keys past Nk are
+  // masked afterwards (MASK builds only)
+  auto qk_init = [&](f32x16& sa) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sa[r] = sb[r] = 0.f;
+    for (int r = 0; r < 16; ++r) sa[r] = 0.f;
   };
-  auto qk_sum = [&](const f32x16& sa, const f32x16& sb, int nvalid) {
+  auto qk_mask = [&](const f32x16& sa, int nvalid) {
     f32x16 r16;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) r16[r] = (!MASK || pi23(acc_row(r, lane)) < nvalid) ? sa[r] + sb[r] : -1e30f;
+    for (int r = 0; r < 16; ++r) r16[r] = (!MASK || pi23(acc_row(r, lane)) < nvalid) ? sa[r] : -1e30f;
     return r16;
   };
-  auto qk8 = [&](const F8& k, int half, f32x16& sa, f32x16& sb) {
+  auto qk8 = [&](const F8& k, int half, f32x16& sa) {
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      sa = mfma32(k.f[j], qf[8 * half + j], sa);
-      sb = mfma32(k.f[j + 1], qf[8 * half + j + 1], sb);
-    }
+    for (int j = 0; j < 8; ++j) sa = mfma32(k.f[j], qf[8 * half + j], sa);
   };
 
   f32x16 o[8];
@@ -294,22 +295,20 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
 
   if (n > 0) {
     issue(0);
-    if (n > 1) issue(1);
-    if (n > 2) issue(2);
-    if (n > 2) wait_vm<16>();
-    else if (n > 1) wait_vm<8>();
-    else wait_vm<0>();
+    issue(1);
+    issue(2);
+    wait_vm<16>();
     __builtin_amdgcn_s_barrier();
     f32x16 s;
     {
       const F8 ka = read_k8(0, 0);
       const F8 kb = read_k8(0, 1);
       __builtin_amdgcn_sched_barrier(0);
-      f32x16 sa, sb;
-      qk_init(sa, sb);
-      qk8(ka, 0, sa, sb);
-      qk8(kb, 1, sa, sb);
-      s = qk_sum(sa, sb, p.Nk - t_lo * 32);
+      f32x16 sa;
+      qk_init(sa);
+      qk8(ka, 0, sa);
+      qk8(kb, 1, sa);
+      s = qk_mask(sa, p.Nk - t_lo * 32);
     }
     float tmax = rowmax(s);
     int i = 0;
@@ -330,22 +329,23 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
         // here: s / tmax belong to tile i and tmax <= m_ref + RESCALE_THR on every lane
         // tile i+1 landed (tile i+2 may stay in flight); every wave is past tile i-1 -> stage (i-1) % NST is free
         if (ABL != 2) {
-          if (i + 2 < n) wait_vm<8>();
-          else wait_vm<0>();
+          wait_vm<8>();
           __builtin_amdgcn_s_barrier();
         }
-        if (ABL != 1 && i + 3 < n) issue(i + 3);
         // next tile's scores (garbage past the last tile: never used) run beside this tile's exponentials
         const F8 ka = read_k8(i + 1, 0);
         const F8 kb = read_k8(i + 1, 1);
         const F8 va = read_v8(i, 0);
         const F8 vb = read_v8(i, 1);
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 sa, sb;
-        qk_init(sa, sb);
+        // LDS-DMA pieces are expensive to issue (60+ cycles each): they go out one per pair of MFMAs instead of as a
+        // burst behind the barrier, where the MFMA pipe would sit idle under them
+        if (ABL != 1) issue(i + 3);
+        f32x16 sa;
+        qk_init(sa);
         if (ABL != 5) {
-          qk8(ka, 0, sa, sb);
-          qk8(kb, 1, sa, sb);
+          qk8(ka, 0, sa);
+          qk8(kb, 1, sa);
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(ka.f[j]), "v"(kb.f[j]));
@@ -360,6 +360,13 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
         }
         psum += __shfl_xor(psum, 32, 64);
         l_run += psum;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                    // QK^T phase schedule: 2 MFMA, 1 LDS-DMA piece, a slice of the VALU
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- O^T += V^T P^T, beside the mask / row maximum of the next tile's scores
         if (ABL != 4) {
 #pragma unroll
@@ -377,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
           for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(va.f[j]), "v"(vb.f[j]));
           asm volatile("" ::"v"(pf[0]), "v"(pf[1]));
         }
-        s = qk_sum(sa, sb, p.Nk - (t_lo + i + 1) * 32);
+        s = qk_mask(sa, p.Nk - (t_lo + i + 1) * 32);
         tmax = rowmax(s);
         ++i;
         if (i >= n) { done = true; break; }
@@ -386,6 +393,7 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
       if (done) break;
     }
   }
+  wait_vm<0>();                                          // the trailing (duplicate) DMA pieces must land before the LDS is released
   const float m_run = m_ref;
 
   // ---- partial results
@@ -440,7 +448,8 @@ hipError_t flash256_init() {
 // v3 runs one 128-query workgroup per CU: pick the KV split count that makes the grid one full wave of 256 workgroups
 int flash256_pick_splits(int Nq, int Nk) {
   const int tiles = (Nk + 31) / 32, qblocks = Nq / 128 > 0 ? Nq / 128 : 1;
-  int s = (256 + qblocks - 1) / qblocks;
+  static const int target_wgs = getenv("SAM2MI_FLASH_WGS") ? atoi(getenv("SAM2MI_FLASH_WGS")) : 256;     // tuning
+  int s = (target_wgs + qblocks - 1) / qblocks;
   if (s > 16) s = 16;
   if (s > tiles) s = tiles;
   return s < 1 ? 1 : s;

@@ -278,16 +278,11 @@ __global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnPa
     return v;
   };
   auto qk = [&](const KF& k) {
-    f32x16 sa, sb;
+    f32x16 sa;                     // one chain: a single accumulation chain of this MFMA issues at full rate
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sa[r] = sb[r] = 0.f;
-    sa = mfma32(k.f[0], qf[0], sa);
-    sb = mfma32(k.f[1], qf[1], sb);
-    sa = mfma32(k.f[2], qf[2], sa);
-    sb = mfma32(k.f[3], qf[3], sb);
-    sa = mfma32(k.f[4], qf[4], sa);
+    for (int r = 0; r < 16; ++r) sa[r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sa[r] += sb[r];
+    for (int ks = 0; ks < 5; ++ks) sa = mfma32(k.f[ks], qf[ks], sa);
     return sa;
   };
   auto rowmax = [&](const f32x16& s) {
