@@ -38,7 +38,7 @@ CLIP_GFLOP_PROPAGATE = 240450.0          # algorithmic GFLOP of one 100-frame pr
 
 def _pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE and
-    WRITE_SIZE runs, gfx950 x2 fetch correction; profiles/r01_b_pmc_traffic.md).  PMC collection cannot run inside the
+    WRITE_SIZE runs, gfx950 x2 fetch correction; profiles/r01_c_pmc_traffic.md).  PMC collection cannot run inside the
     timed process, so this is the last committed measurement, or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
