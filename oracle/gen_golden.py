@@ -152,6 +152,29 @@ def gen_video():
     print("video done", time.time() - t0)
 
 
+@torch.inference_mode()
+def gen_tiny():
+    """BASELINE.json configs[0]: SAM2.1-hiera-tiny image predictor, one 1024^2 frame, torch backend on the CPU - the
+    reference's own CPU-runnable case.  Synthetic tiny weights, image RandomState(0), one positive click at (512, 512)."""
+    cfg = get_config("tiny")
+    sd = synthetic_state_dict(cfg, seed=0)
+    model = build_reference_model(cfg, "base", sd)            # also puts /root/reference/sam2 on sys.path (with the shims)
+    from sam2.sam2_image_predictor import SAM2ImagePredictor
+    pred = SAM2ImagePredictor(model)
+    img = np.random.RandomState(0).randint(0, 256, (1024, 1024, 3)).astype(np.uint8)
+    t0 = time.time()
+    pred.set_image(img)
+    masks, ious, low = pred.predict(point_coords=np.array([CLICK], np.float32), point_labels=np.array([1], np.int32),
+                                    multimask_output=True, return_logits=True)
+    store = {}
+    pack(store, "tiny/masks_logits", torch.from_numpy(np.asarray(masks)), 40000)
+    pack(store, "tiny/ious", torch.from_numpy(np.asarray(ious)), 16)
+    pack(store, "tiny/low_res", torch.from_numpy(np.asarray(low)), 40000)
+    pack(store, "tiny/image_embed", pred._features["image_embed"], 20000)
+    np.savez_compressed(os.path.join(GOLD, "tiny_image.npz"), **store)
+    print("tiny done", time.time() - t0, "ious", np.asarray(ious))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["plugs", "video"]
     os.makedirs(GOLD, exist_ok=True)
@@ -160,3 +183,5 @@ if __name__ == "__main__":
         gen_plugs()
     if "video" in which:
         gen_video()
+    if "tiny" in which:
+        gen_tiny()

@@ -79,3 +79,27 @@ def test_sam_heads(mm, sd_large, cfg_large, golden_plugs):
                 high="high_res_masks", obj_ptr="obj_ptr", obj_score="object_score_logits")
     for g, k in keys.items():
         _check(golden_plugs, f"samheads_mm{int(mm)}/{g}", o[k], atol=1e-3)
+
+
+def test_tiny_image_predictor_config0():
+    """BASELINE.json configs[0] (the reference's own CPU-runnable case): SAM2.1-hiera-tiny image predictor, one 1024^2
+    frame, one positive click, multimask output - the oracle against the REAL reference's SAM2ImagePredictor
+    (torch backend, CPU; tests/golden/tiny_image.npz from oracle/gen_golden.py tiny).  Exercises the padded 14x14 / 7x7
+    windows and the 1-head stem that hiera-large does not have."""
+    import os
+    import numpy as np
+    from sam2_opt_amd.config import get_config
+    from sam2_opt_amd.weights import synthetic_state_dict
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_image.npz"))
+    cfg = get_config("tiny")
+    sd = synthetic_state_dict(cfg, seed=0)
+    img = np.random.RandomState(0).randint(0, 256, (1024, 1024, 3)).astype(np.uint8)
+    img01 = torch.from_numpy(img).permute(2, 0, 1)[None].float() / 255.0
+    with torch.inference_mode():
+        feats = R.set_image_e2e(img01, sd, cfg)
+        masks, ious, low = R.image_predict(feats, torch.tensor([[[512.0, 512.0]]]), torch.tensor([[1]], dtype=torch.int32),
+                                           True, (1024, 1024), sd, cfg)
+    _check(gold, "tiny/image_embed", feats[2], atol=1e-4)
+    _check(gold, "tiny/ious", ious[0], atol=1e-5)
+    _check(gold, "tiny/low_res", low[0], atol=1e-4)
+    _check(gold, "tiny/masks_logits", masks[0], atol=1e-4)
