@@ -148,10 +148,12 @@ int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, const sam2m
                        int run_mem_encoder, const sam2mi_frame_out* out);
 
 /* Image predictor: prompt encoder + mask decoder on a cached frame (SAM2ImagePredictor._predict,
- * sam2_image_predictor.py:487-589: features + no_mem_embed, no object-score gating).  One prompt of Np points
- * (labels 0/1 points, 2/3 box corners).  multimask: masks_out (3,256,256) + iou_out (3); otherwise the dynamic
- * stability fallback picks one: masks_out (1,256,256) + iou_out (1). */
-int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int Np,
+ * sam2_image_predictor.py:487-589: features + no_mem_embed, no object-score gating).  N independent prompts of Np points each
+ * on the SAME image (coords [N,Np,2] pixels at image_size, labels [N,Np]: 0/1 points, 2/3 box corners) - the repeat_image case
+ * (:564-579) and the 64-prompt batches of the automatic mask generator - run as one batched decoder pass (chunks of 16).
+ * multimask: masks_out (N,3,256,256) + iou_out (N,3); otherwise the dynamic stability fallback picks one per prompt:
+ * masks_out (N,1,256,256) + iou_out (N,1). */
+int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int N, int Np,
                          int multimask, float* masks_out, float* iou_out);
 
 /* Bilinear resize (align_corners=False) of a (H_in,W_in) fp32 map, F.interpolate semantics

@@ -53,10 +53,11 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const float* __restrict
 // their online-softmax states are merged through LDS.
 __global__ __launch_bounds__(1024) void t2i_attn_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                         const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo,
-                                                        int Tq, int Tk, int heads) {
+                                                        int Tq, int Tk, int heads, size_t q_bs, size_t kv_bs, size_t o_bs) {
   constexpr int HD = 16;
   __shared__ float sm[16], sl[16], so[16][HD];
   const int qi = blockIdx.x % Tq, h = blockIdx.x / Tq;
+  q += blockIdx.y * q_bs; k += blockIdx.y * kv_bs; v += blockIdx.y * kv_bs; out += blockIdx.y * o_bs;     // batch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   f32x4 qr[4];
 #pragma unroll
@@ -110,10 +111,11 @@ __global__ __launch_bounds__(1024) void t2i_attn_kernel(const float* __restrict_
 // keys/values of the head broadcast from LDS.
 __global__ __launch_bounds__(256) void i2t_attn_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                        const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo,
-                                                       int Tq, int Tk, int heads) {
+                                                       int Tq, int Tk, int heads, size_t q_bs, size_t kv_bs, size_t o_bs) {
   constexpr int HD = 16;
   __shared__ float sk[64 * 128], sv[64 * 128];           // [Tk][heads*HD], heads*HD <= 128
   const int C = heads * HD;
+  q += blockIdx.y * q_bs; k += blockIdx.y * kv_bs; v += blockIdx.y * kv_bs; out += blockIdx.y * o_bs;     // batch
   for (int i = threadIdx.x; i < Tk * C; i += 256) {
     sk[i] = k[(size_t)(i / C) * ldk + i % C];
     sv[i] = v[(size_t)(i / C) * ldv + i % C];
@@ -157,12 +159,14 @@ hipError_t small_attn_launch(const float* q, int ldq, const float* k, int ldk, c
   const long tasks = (long)batch * heads * Tq;
   const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
   const bool al = !(ldq & 3) && !(ldk & 3) && !(ldv & 3) && !(ldo & 3);
-  if (hd == 16 && batch == 1 && al && Tq <= 64 && Tk >= 1024) {
-    t2i_attn_kernel<<<dim3(Tq * heads), dim3(1024), 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, Tq, Tk, heads);
+  if (hd == 16 && batch <= 65535 && al && Tq <= 64 && Tk >= 1024) {
+    t2i_attn_kernel<<<dim3(Tq * heads, batch), dim3(1024), 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, Tq, Tk, heads, q_bstride,
+                                                                        kv_bstride, o_bstride);
     return hipGetLastError();
   }
-  if (hd == 16 && batch == 1 && al && Tk <= 64 && heads * 16 <= 128 && Tq >= 1024) {
-    i2t_attn_kernel<<<dim3((Tq * heads + 255) / 256), dim3(256), 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, Tq, Tk, heads);
+  if (hd == 16 && batch <= 65535 && al && Tk <= 64 && heads * 16 <= 128 && Tq >= 1024) {
+    i2t_attn_kernel<<<dim3((Tq * heads + 255) / 256, batch), dim3(256), 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, Tq, Tk, heads,
+                                                                                     q_bstride, kv_bstride, o_bstride);
     return hipGetLastError();
   }
   if (hd == 16)

@@ -197,6 +197,14 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& blk, 
 
 // engine_track.hip
 int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const float* curr_pos, int Nk, int n_rope, float* out32);
-int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* keys_tok, const float* dense_tok, int dense_rows,
-                    const float* pos_tok, const float* tokens, int T, const float* hr0_tok, const float* hr1_tok);
+constexpr int DEC_MAX_N = 16;     // prompts / objects per batched mask-decoder call (workspace size)
+struct DecoderIn {
+  const float* keys_tok; size_t keys_stride;                    // floats between prompts; 0: one image for all (repeat_image)
+  const float* dense_tok; int dense_rows; size_t dense_stride;  // dense prompt embedding (null: none)
+  const float* pos_tok; bool pos_shared;                         // [4096,256] shared by all prompts, or [N,4096,256]
+  const float* tokens;                                           // [N,T,256]
+  const float* hr0_tok; size_t hr0_stride;                       // [65536,32] per prompt, stride 0: shared
+  const float* hr1_tok; size_t hr1_stride;                       // [16384,64]
+};
+int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, int T);
 int memenc_forward(sam2mi_ctx* ctx, hipStream_t s, const float* feat2_tok, const float* mask1024, float* out_tok64);

@@ -104,17 +104,20 @@ extern "C" int sam2mi_mask_decoder(sam2mi_ctx* ctx, void* stream, const float* s
                                    float* mask_tokens_out, float* object_score_logits) {
   REQUIRE_READY();
   hipStream_t s = S(stream);
-  for (int n = 0; n < N; ++n) {
-    // NCHW -> token-major
-    CHK(transpose_f32_launch(src + (size_t)n * 256 * 4096, ctx->p_d, 1, 256, 4096, s));
-    CHK(transpose_f32_launch(pos_src + (size_t)n * 256 * 4096, ctx->d_big3, 1, 256, 4096, s));
-    CHK(transpose_f32_launch(hr0 + (size_t)n * 32 * 65536, ctx->p_a, 1, 32, 65536, s));
-    CHK(transpose_f32_launch(hr1 + (size_t)n * 64 * 16384, ctx->p_c, 1, 64, 16384, s));
-    CHKI(decoder_forward(ctx, s, ctx->p_d, nullptr, 0, ctx->d_big3, tokens + (size_t)n * T * 256, T, ctx->p_a, ctx->p_c));
-    if (masks) CHK(hipMemcpyAsync(masks + (size_t)n * 4 * 65536, ctx->d_masks, (size_t)4 * 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (iou_pred) CHK(hipMemcpyAsync(iou_pred + n * 4, ctx->d_iou, 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (mask_tokens_out) CHK(hipMemcpyAsync(mask_tokens_out + (size_t)n * 1024, ctx->d_mtok, 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (object_score_logits) CHK(hipMemcpyAsync(object_score_logits + n, ctx->d_obj, sizeof(float), hipMemcpyDeviceToDevice, s));
+  for (int n0 = 0; n0 < N; n0 += DEC_MAX_N) {
+    const int nb = std::min(DEC_MAX_N, N - n0);
+    // NCHW -> token-major, nb prompts back to back
+    CHK(transpose_f32_launch(src + (size_t)n0 * 256 * 4096, ctx->p_d, nb, 256, 4096, s));
+    CHK(transpose_f32_launch(hr0 + (size_t)n0 * 32 * 65536, ctx->p_a, nb, 32, 65536, s));
+    CHK(transpose_f32_launch(hr1 + (size_t)n0 * 64 * 16384, ctx->p_c, nb, 64, 16384, s));
+    CHK(transpose_f32_launch(pos_src + (size_t)n0 * 256 * 4096, ctx->d_big3, nb, 256, 4096, s));
+    DecoderIn in{ctx->p_d, (size_t)4096 * 256, nullptr, 0, 0, ctx->d_big3, false, tokens + (size_t)n0 * T * 256,
+                 ctx->p_a, (size_t)65536 * 32, ctx->p_c, (size_t)16384 * 64};
+    CHKI(decoder_forward(ctx, s, in, nb, T));
+    if (masks) CHK(hipMemcpyAsync(masks + (size_t)n0 * 4 * 65536, ctx->d_masks, (size_t)nb * 4 * 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (iou_pred) CHK(hipMemcpyAsync(iou_pred + n0 * 4, ctx->d_iou, (size_t)nb * 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (mask_tokens_out) CHK(hipMemcpyAsync(mask_tokens_out + (size_t)n0 * 1024, ctx->d_mtok, (size_t)nb * 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (object_score_logits) CHK(hipMemcpyAsync(object_score_logits + n0, ctx->d_obj, (size_t)nb * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   return 0;
 }
@@ -218,8 +221,9 @@ static int sam_heads_finish(sam2mi_ctx* ctx, hipStream_t s, int multimask, int b
   {
     Mlp3Batch B;
     B.n = 1;
+    B.reps = 1;
     Mlp3Group& g = B.g[0];
-    g.x = ctx->d_tok_sel; g.y = bk.obj_ptr; g.n_out = 256; g.sigmoid_out = 0;
+    g.x = ctx->d_tok_sel; g.y = bk.obj_ptr; g.n_out = 256; g.sigmoid_out = 0; g.x_rep_stride = 0; g.y_rep_stride = 0;
     for (int i = 0; i < 3; ++i) { g.W[i] = ctx->ptr_proj[i].w; g.b[i] = ctx->ptr_proj[i].b; }
     CHK(mlp3_launch(B, s));
   }
@@ -242,22 +246,27 @@ static int sam_heads_finish(sam2mi_ctx* ctx, hipStream_t s, int multimask, int b
   return 0;
 }
 
-static int build_tokens(sam2mi_ctx* ctx, hipStream_t s, const float* coords, const int32_t* labels, int Np, int& T) {
-  // tokens = [obj_score, iou, mask x4] ++ sparse(points + pad)   (mask_decoder.py:186-202)
+// tokens[n] = [obj_score, iou, mask x4] ++ sparse(points of prompt n + pad)   (mask_decoder.py:186-202), N prompts of Np points
+static int build_tokens(sam2mi_ctx* ctx, hipStream_t s, const float* coords, const int32_t* labels, int N, int Np, int& T) {
   if (Np + 1 + 6 > 64) return sam2mi_set_error(ctx, "build_tokens", "too many points");
-  CHK(hipMemcpyAsync(ctx->d_sparse, ctx->out_tokens, 6 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  const float* pts = nullptr;
-  const int* lab = nullptr;
-  if (Np > 0) {
-    CHK(hipMemcpyAsync(ctx->d_pts, coords, (size_t)Np * 2 * sizeof(float), hipMemcpyDefault, s));
-    CHK(hipMemcpyAsync(ctx->d_labels, labels, (size_t)Np * sizeof(int), hipMemcpyDefault, s));
-    pts = ctx->d_pts;
-    lab = ctx->d_labels;
-  }
-  CHK(point_embed_launch(pts, lab, Np, ctx->gauss, ctx->point_emb4, ctx->not_a_point, (float)ctx->cfg.image_size,
-                         ctx->d_sparse + 6 * 256, s));
+  if (N < 1 || N > DEC_MAX_N) return sam2mi_set_error(ctx, "build_tokens", "prompt batch out of range");
   T = 6 + Np + 1;
+  if (Np > 0) {
+    CHK(hipMemcpyAsync(ctx->d_pts, coords, (size_t)N * Np * 2 * sizeof(float), hipMemcpyDefault, s));
+    CHK(hipMemcpyAsync(ctx->d_labels, labels, (size_t)N * Np * sizeof(int), hipMemcpyDefault, s));
+  }
+  for (int n = 0; n < N; ++n) {
+    float* tok = ctx->d_sparse + (size_t)n * T * 256;
+    CHK(hipMemcpyAsync(tok, ctx->out_tokens, 6 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CHK(point_embed_launch(Np > 0 ? ctx->d_pts + (size_t)n * Np * 2 : nullptr, Np > 0 ? ctx->d_labels + (size_t)n * Np : nullptr, Np, ctx->gauss,
+                           ctx->point_emb4, ctx->not_a_point, (float)ctx->cfg.image_size, tok + 6 * 256, s));
+  }
   return 0;
+}
+
+// one image (token-major pix features + its high-res features), N prompt token sets in ctx->d_sparse
+static DecoderIn one_image_in(sam2mi_ctx* ctx, const sam2mi_ctx::FeatSlot& f) {
+  return DecoderIn{ctx->t_pix, 0, ctx->no_mask_embed, 1, 0, ctx->dense_pe, true, ctx->d_sparse, f.fpn0, 0, f.fpn1, 0};
 }
 
 extern "C" int sam2mi_video_click(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int Np,
@@ -270,32 +279,42 @@ extern "C" int sam2mi_video_click(sam2mi_ctx* ctx, void* stream, int feat_slot, 
   // pix_feat = feat + no_mem_embed (directly_add_no_mem_embed, sam2_base_official.py:953-957)
   CHK(cast_add_launch(f.feat2, 256, ctx->no_mem_embed, 256, 1, 1.f, 4096, 256, nullptr, 0, ctx->t_pix, 256, s));
   int T = 0;
-  CHKI(build_tokens(ctx, s, coords, labels, Np, T));
-  CHKI(decoder_forward(ctx, s, ctx->t_pix, ctx->no_mask_embed, 1, ctx->dense_pe, ctx->d_sparse, T, f.fpn0, f.fpn1));
+  CHKI(build_tokens(ctx, s, coords, labels, 1, Np, T));
+  CHKI(decoder_forward(ctx, s, one_image_in(ctx, f), 1, T));
   if (out && out->pix_feat) CHK(hipMemcpyAsync(out->pix_feat, ctx->t_pix, (size_t)4096 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
   return sam_heads_finish(ctx, s, multimask, bank_slot, out);
 }
 
-extern "C" int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int Np,
+extern "C" int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int N, int Np,
                                     int multimask, float* masks_out, float* iou_out) {
   REQUIRE_READY();
   hipStream_t s = S(stream);
   if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size()) return sam2mi_set_error(ctx, __func__, "slot out of range");
+  if (N < 1) return sam2mi_set_error(ctx, __func__, "no prompts");
   const sam2mi_ctx::FeatSlot& f = ctx->feats[feat_slot];
   CHK(cast_add_launch(f.feat2, 256, ctx->no_mem_embed, 256, 1, 1.f, 4096, 256, nullptr, 0, ctx->t_pix, 256, s));
-  int T = 0;
-  CHKI(build_tokens(ctx, s, coords, labels, Np, T));
-  CHKI(decoder_forward(ctx, s, ctx->t_pix, ctx->no_mask_embed, 1, ctx->dense_pe, ctx->d_sparse, T, f.fpn0, f.fpn1));
-  if (multimask) {
-    if (masks_out) CHK(hipMemcpyAsync(masks_out, ctx->d_masks + 65536, (size_t)3 * 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (iou_out) CHK(hipMemcpyAsync(iou_out, ctx->d_iou + 1, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  } else {
-    // MaskDecoder._dynamic_multimask_via_stability (mask_decoder.py:346-382); "object present" forced on: no gating here
-    CHK(fill_f32_launch(ctx->d_t1, 1.f, 1, s));
-    CHK(select_mask_launch(ctx->d_masks, ctx->d_iou, ctx->d_t1, ctx->d_mtok, 0, ctx->d_best + 2, 0.05f, 0.98f, nullptr,
-                           ctx->d_low_sel, ctx->d_tok_sel, ctx->d_best, ctx->d_iou_sel, s));
-    if (masks_out) CHK(hipMemcpyAsync(masks_out, ctx->d_low_sel, 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (iou_out) CHK(hipMemcpyAsync(iou_out, ctx->d_iou_sel, sizeof(float), hipMemcpyDeviceToDevice, s));
+  // N independent prompts on ONE image (repeat_image, sam2_image_predictor.py:564-579): batched through the decoder
+  for (int n0 = 0; n0 < N; n0 += DEC_MAX_N) {
+    const int nb = std::min(DEC_MAX_N, N - n0);
+    int T = 0;
+    CHKI(build_tokens(ctx, s, coords + (size_t)n0 * Np * 2, labels + (size_t)n0 * Np, nb, Np, T));
+    CHKI(decoder_forward(ctx, s, one_image_in(ctx, f), nb, T));
+    if (multimask) {
+      if (masks_out)
+        CHK(hipMemcpy2DAsync(masks_out + (size_t)n0 * 3 * 65536, (size_t)3 * 65536 * sizeof(float), ctx->d_masks + 65536, (size_t)4 * 65536 * sizeof(float),
+                             (size_t)3 * 65536 * sizeof(float), nb, hipMemcpyDeviceToDevice, s));
+      if (iou_out)
+        CHK(hipMemcpy2DAsync(iou_out + (size_t)n0 * 3, 3 * sizeof(float), ctx->d_iou + 1, 4 * sizeof(float), 3 * sizeof(float), nb, hipMemcpyDeviceToDevice, s));
+    } else {
+      // MaskDecoder._dynamic_multimask_via_stability (mask_decoder.py:346-382); "object present" forced on: no gating here
+      CHK(fill_f32_launch(ctx->d_t1, 1.f, 1, s));
+      for (int n = 0; n < nb; ++n) {
+        CHK(select_mask_launch(ctx->d_masks + (size_t)n * 4 * 65536, ctx->d_iou + n * 4, ctx->d_t1, ctx->d_mtok + (size_t)n * 1024, 0, ctx->d_best + 2, 0.05f,
+                               0.98f, nullptr, ctx->d_low_sel, ctx->d_tok_sel, ctx->d_best, ctx->d_iou_sel, s));
+        if (masks_out) CHK(hipMemcpyAsync(masks_out + (size_t)(n0 + n) * 65536, ctx->d_low_sel, 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (iou_out) CHK(hipMemcpyAsync(iou_out + (n0 + n), ctx->d_iou_sel, sizeof(float), hipMemcpyDeviceToDevice, s));
+      }
+    }
   }
   return 0;
 }
@@ -355,11 +374,11 @@ extern "C" int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, 
   CHKI(memattn_forward(ctx, s, f.feat2, ctx->sine_pe_tok64, L * 4096 + P, L * 4096, ctx->t_pix));
   if (out && out->pix_feat) CHK(hipMemcpyAsync(out->pix_feat, ctx->t_pix, (size_t)4096 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
   int T = 0;
-  CHKI(build_tokens(ctx, s, nullptr, nullptr, 0, T));      // no prompt: one padding point (label -1) + pad
+  CHKI(build_tokens(ctx, s, nullptr, nullptr, 1, 0, T));      // no prompt: one padding point (label -1) + pad
   // _forward_sam_heads pads with ONE (0,0)/-1 point and the prompt encoder appends another pad point (:395-401, prompt_encoder.py:133-137)
   CHK(hipMemcpyAsync(ctx->d_sparse + (size_t)T * 256, ctx->d_sparse + (size_t)(T - 1) * 256, 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
   T += 1;
-  CHKI(decoder_forward(ctx, s, ctx->t_pix, ctx->no_mask_embed, 1, ctx->dense_pe, ctx->d_sparse, T, f.fpn0, f.fpn1));
+  CHKI(decoder_forward(ctx, s, one_image_in(ctx, f), 1, T));
   CHKI(sam_heads_finish(ctx, s, 1, bank_slot, out, run_mem_encoder ? feat_slot : -1));
   return 0;
 }

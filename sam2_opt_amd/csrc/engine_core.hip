@@ -632,38 +632,38 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ALLOC(ctx->t_ptr_pos, float, 128 * 64);
   ALLOC(ctx->t_pix, float, 4096 * 256);
   // decoder
-  ALLOC(ctx->d_keys, float, 4096 * 256);
-  ALLOC(ctx->d_keys16, half_t, 4096 * 256);
-  ALLOC(ctx->d_kpe16, half_t, 4096 * 256);
-  ALLOC(ctx->d_tok, float, 64 * 256);
-  ALLOC(ctx->d_tokpe, float, 64 * 256);
-  ALLOC(ctx->d_t1, float, 64 * 2048);
-  ALLOC(ctx->d_t2, float, 64 * 2048);
-  ALLOC(ctx->d_t3, float, 64 * 2048);
-  ALLOC(ctx->d_t4, float, 64 * 2048);
-  ALLOC(ctx->d_big1, float, 4096 * 256);
-  ALLOC(ctx->d_big2, float, 4096 * 256);
-  ALLOC(ctx->d_big3, float, 4096 * 256);
-  ALLOC(ctx->d_big16, half_t, 4096 * 256);
-  ALLOC(ctx->d_tokens_in, float, 64 * 256);
-  ALLOC(ctx->d_sparse, float, 64 * 256);
-  ALLOC(ctx->d_up1_16, half_t, 16384 * 64);
-  ALLOC(ctx->d_up2_16, half_t, 65536 * 32);
-  ALLOC(ctx->d_g, float, 16384 * 128);
-  ALLOC(ctx->d_hyper, float, 4 * 32);
-  ALLOC(ctx->d_hyper16, half_t, 8 * 32);
-  ALLOC(ctx->d_masks, float, 4 * 65536);
-  ALLOC(ctx->d_iou, float, 8);
-  ALLOC(ctx->d_obj, float, 8);
-  ALLOC(ctx->d_mtok, float, 4 * 256);
+  ALLOC(ctx->d_keys, float, (size_t)DEC_MAX_N * 4096 * 256);
+  ALLOC(ctx->d_keys16, half_t, (size_t)DEC_MAX_N * 4096 * 256);
+  ALLOC(ctx->d_kpe16, half_t, (size_t)DEC_MAX_N * 4096 * 256);
+  ALLOC(ctx->d_tok, float, (size_t)DEC_MAX_N * 64 * 256);
+  ALLOC(ctx->d_tokpe, float, (size_t)DEC_MAX_N * 64 * 256);
+  ALLOC(ctx->d_t1, float, (size_t)DEC_MAX_N * 64 * 2048);
+  ALLOC(ctx->d_t2, float, (size_t)DEC_MAX_N * 64 * 2048);
+  ALLOC(ctx->d_t3, float, (size_t)DEC_MAX_N * 64 * 2048);
+  ALLOC(ctx->d_t4, float, (size_t)DEC_MAX_N * 64 * 2048);
+  ALLOC(ctx->d_big1, float, (size_t)DEC_MAX_N * 4096 * 256);
+  ALLOC(ctx->d_big2, float, (size_t)DEC_MAX_N * 4096 * 256);
+  ALLOC(ctx->d_big3, float, (size_t)DEC_MAX_N * 4096 * 256);
+  ALLOC(ctx->d_big16, half_t, (size_t)DEC_MAX_N * 4096 * 256);
+  ALLOC(ctx->d_tokens_in, float, (size_t)DEC_MAX_N * 64 * 256);
+  ALLOC(ctx->d_sparse, float, (size_t)DEC_MAX_N * 64 * 256);
+  ALLOC(ctx->d_up1_16, half_t, (size_t)DEC_MAX_N * 16384 * 64);
+  ALLOC(ctx->d_up2_16, half_t, (size_t)DEC_MAX_N * 65536 * 32);
+  ALLOC(ctx->d_g, float, (size_t)DEC_MAX_N * 16384 * 128);
+  ALLOC(ctx->d_hyper, float, (size_t)DEC_MAX_N * 4 * 32);
+  ALLOC(ctx->d_hyper16, half_t, (size_t)(DEC_MAX_N * 4 + 32) * 32);
+  ALLOC(ctx->d_masks, float, (size_t)DEC_MAX_N * 4 * 65536);
+  ALLOC(ctx->d_iou, float, DEC_MAX_N * 4 + 8);
+  ALLOC(ctx->d_obj, float, DEC_MAX_N + 8);
+  ALLOC(ctx->d_mtok, float, (size_t)DEC_MAX_N * 4 * 256);
   ALLOC(ctx->d_low_multi, float, 3 * 65536);
   ALLOC(ctx->d_low_sel, float, 65536);
   ALLOC(ctx->d_tok_sel, float, 256);
   ALLOC(ctx->d_best, int, 4);
   ALLOC(ctx->d_iou_sel, float, 4);
   ALLOC(ctx->d_ptr, float, 256);
-  ALLOC(ctx->d_pts, float, 64 * 2);
-  ALLOC(ctx->d_labels, int, 64);
+  ALLOC(ctx->d_pts, float, (size_t)DEC_MAX_N * 64 * 2);
+  ALLOC(ctx->d_labels, int, (size_t)DEC_MAX_N * 64);
   ALLOC(ctx->dense_pe, float, 4096 * 256);
   // memory encoder
   ALLOC(ctx->m_mask, float, 1024 * 1024);
@@ -682,10 +682,10 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ALLOC(ctx->m_out, float, 4096 * 64);
   ALLOC(ctx->m_pix16, half_t, 4096 * 256);
   // plug scratch
-  ALLOC(ctx->p_a, float, (size_t)65536 * 32);
+  ALLOC(ctx->p_a, float, (size_t)DEC_MAX_N * 65536 * 32);
   ALLOC(ctx->p_b, float, (size_t)65536 * 32);
-  ALLOC(ctx->p_c, float, (size_t)16384 * 64);
-  ALLOC(ctx->p_d, float, (size_t)4096 * 256);
+  ALLOC(ctx->p_c, float, (size_t)DEC_MAX_N * 16384 * 64);
+  ALLOC(ctx->p_d, float, (size_t)DEC_MAX_N * 4096 * 256);
   // video caches
   ctx->feats.resize(c.feat_slots);
   for (auto& f : ctx->feats) {

@@ -98,9 +98,9 @@ static SmallLin mk_lin(const float* x, int ldx, const Lin32& L, float* y, int ld
                        int ldres = 0) {
   return SmallLin{x, L.w, L.b, y, res, ldx, ldy, ldres, T, L.N, L.K, act};
 }
-static Mlp3Group mk_mlp3(const float* x, const Lin32* L, float* y, int sigmoid_out) {
+static Mlp3Group mk_mlp3(const float* x, const Lin32* L, float* y, int sigmoid_out, long x_rep_stride = 0, long y_rep_stride = 0) {
   Mlp3Group g;
-  g.x = x; g.y = y; g.n_out = L[2].N; g.sigmoid_out = sigmoid_out;
+  g.x = x; g.y = y; g.n_out = L[2].N; g.sigmoid_out = sigmoid_out; g.x_rep_stride = x_rep_stride; g.y_rep_stride = y_rep_stride;
   for (int i = 0; i < 3; ++i) { g.W[i] = L[i].w; g.b[i] = L[i].b; }
   return g;
 }
@@ -110,134 +110,137 @@ static int tok_ln(sam2mi_ctx* ctx, hipStream_t s, float* x, const Norm& n, int T
   return 0;
 }
 
-// token -> image attention: q tokens (+pe) against image keys (f16 operands in d_kpe16 / d_keys16)
-static int t2i_attention(sam2mi_ctx* ctx, hipStream_t s, const Lin32& Wq, const Lin16& Wk, const Lin16& Wv, const Lin32& Wo, int T) {
-  float* q = ctx->d_tok;            // [T,256]
+// token -> image attention for N prompts: q tokens (+pe) against each prompt's image keys (f16 operands in d_kpe16 / d_keys16)
+static int t2i_attention(sam2mi_ctx* ctx, hipStream_t s, const Lin32& Wq, const Lin16& Wk, const Lin16& Wv, const Lin32& Wo, int N, int T) {
+  float* q = ctx->d_tok;            // [N*T,256]
+  const int R = N * T;
   // qq = q_proj(q + qpe)
-  CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, T, 256, nullptr, 0, ctx->d_tokpe, 256, s));
-  CHKI(tok_linear(ctx, s, ctx->d_tokpe, 256, Wq, ctx->d_t1, 128, T, 0));
-  GemmParams pk = lin_params(ctx->d_kpe16, 256, 4096, Wk);
+  CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, R, 256, nullptr, 0, ctx->d_tokpe, 256, s));
+  CHKI(tok_linear(ctx, s, ctx->d_tokpe, 256, Wq, ctx->d_t1, 128, R, 0));
+  GemmParams pk = lin_params(ctx->d_kpe16, 256, N * 4096, Wk);
   pk.out32 = ctx->d_big1; pk.ld32 = 128;
   CHKI(run_gemm(ctx, s, pk));
-  GemmParams pv = lin_params(ctx->d_keys16, 256, 4096, Wv);
+  GemmParams pv = lin_params(ctx->d_keys16, 256, N * 4096, Wv);
   pv.out32 = ctx->d_big2; pv.ld32 = 128;
   CHKI(run_gemm(ctx, s, pv));
-  CHK(small_attn_launch(ctx->d_t1, 128, ctx->d_big1, 128, ctx->d_big2, 128, ctx->d_t2, 128, T, 4096, 8, 16, 1, 0, 0, 0, s));
+  CHK(small_attn_launch(ctx->d_t1, 128, ctx->d_big1, 128, ctx->d_big2, 128, ctx->d_t2, 128, T, 4096, 8, 16, N, (size_t)T * 128,
+                        (size_t)4096 * 128, (size_t)T * 128, s));
   // q = q + out_proj(att)
-  CHKI(tok_linear(ctx, s, ctx->d_t2, 128, Wo, q, 256, T, 0, q, 256));
+  CHKI(tok_linear(ctx, s, ctx->d_t2, 128, Wo, q, 256, R, 0, q, 256));
   return 0;
 }
 
-// refresh the f16 image-side operands from ctx->d_keys: keys16 = f16(keys), kpe16 = f16(keys + pos)
-static int refresh_key_operands(sam2mi_ctx* ctx, hipStream_t s, const float* pos_tok) {
-  CHK(cast_add_launch(ctx->d_keys, 256, nullptr, 0, 0, 0.f, 4096, 256, ctx->d_keys16, 256, nullptr, 0, s));
-  CHK(cast_add_launch(ctx->d_keys, 256, pos_tok, 256, 0, 1.f, 4096, 256, ctx->d_kpe16, 256, nullptr, 0, s));
+// refresh the f16 image-side operands from ctx->d_keys [N*4096,256]: keys16 = f16(keys), kpe16 = f16(keys + pos)
+static int refresh_key_operands(sam2mi_ctx* ctx, hipStream_t s, const float* pos_tok, bool pos_shared, int N) {
+  CHK(cast_add_launch(ctx->d_keys, 256, nullptr, 0, 0, 0.f, N * 4096, 256, ctx->d_keys16, 256, nullptr, 0, s));
+  CHK(cast_add_launch(ctx->d_keys, 256, pos_tok, 256, pos_shared ? 4096 : 0, 1.f, N * 4096, 256, ctx->d_kpe16, 256, nullptr, 0, s));
   return 0;
 }
 
 // MaskDecoder.inference_predict_masks_torch (modeling/sam/mask_decoder.py:262-316) + TwoWayTransformer
-// (sam/transformer.py:98-219) for one object.  keys_tok [4096,256] image embedding (token-major),
-// dense_tok [dense_rows,256] dense prompt embedding added to it (dense_rows = 1: broadcast no_mask_embed,
-// 4096: per-token; null: none), pos_tok [4096,256], tokens [T,256], hr0_tok [65536,32], hr1_tok [16384,64].
-// Results land in ctx->d_masks [4,65536], d_iou [4], d_mtok [4,256], d_obj [1].
-int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* keys_tok, const float* dense_tok, int dense_rows,
-                    const float* pos_tok, const float* tokens, int T, const float* hr0_tok, const float* hr1_tok) {
+// (sam/transformer.py:98-219), batched over N prompts / objects (N <= DEC_MAX_N): every image-side GEMM runs on
+// M = N * 4096 rows and every token-side op on N * T rows.  in.keys_tok [4096,256] image embedding per prompt (token-major;
+// keys_stride 0: one image shared by all prompts, the repeat_image case of sam2_image_predictor.py:564-579),
+// in.dense_tok [dense_rows,256] dense prompt embedding added to it (dense_rows = 1: broadcast no_mask_embed, 4096: per token;
+// null: none), in.pos_tok [4096,256] shared or [N,4096,256], in.tokens [N,T,256], hr0 [65536,32] / hr1 [16384,64] per prompt or shared.
+// Results land in ctx->d_masks [N,4,65536], d_iou [N,4], d_mtok [N,4,256], d_obj [N].
+int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, int T) {
   if (T < 6 || T > 64) return sam2mi_set_error(ctx, "decoder_forward", "token count out of range (6..64)");
+  if (N < 1 || N > DEC_MAX_N) return sam2mi_set_error(ctx, "decoder_forward", "prompt batch out of range (1..DEC_MAX_N)");
+  const int R = N * T, M = N * 4096;
   // src = image_embeddings + dense_prompt_embeddings (mask_decoder.py:216)
-  CHK(cast_add_launch(keys_tok, 256, dense_tok, 256, dense_rows >= 4096 ? 0 : 1, 1.f, 4096, 256, nullptr, 0, ctx->d_keys, 256, s));
-  CHK(hipMemcpyAsync(ctx->d_tokens_in, tokens, (size_t)T * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));   // query_pe
-  CHK(hipMemcpyAsync(ctx->d_tok, tokens, (size_t)T * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  for (int n = 0; n < N; ++n)
+    CHK(cast_add_launch(in.keys_tok + (size_t)n * in.keys_stride, 256, in.dense_tok ? in.dense_tok + (size_t)n * in.dense_stride : nullptr, 256,
+                        in.dense_rows >= 4096 ? 0 : 1, in.dense_tok ? 1.f : 0.f, 4096, 256, nullptr, 0, ctx->d_keys + (size_t)n * 4096 * 256, 256, s));
+  CHK(hipMemcpyAsync(ctx->d_tokens_in, in.tokens, (size_t)R * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));   // query_pe
+  CHK(hipMemcpyAsync(ctx->d_tok, in.tokens, (size_t)R * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
   float* q = ctx->d_tok;
-  const char* stop_env = getenv("SAM2MI_DEC_STOP");
-  const int stop = stop_env ? atoi(stop_env) : -1;
-  int stage = 0;
-#define DBG_STAGE() do { if (stop >= 0 && stage++ == stop) return 0; } while (0)
   for (int l = 0; l < 2; ++l) {
     const DecLayerW& L = ctx->dec[l];
     // ---- token self attention (layer 0: no pe, output replaces the queries; transformer.py:186-193)
     const float* qin = q;
     if (l > 0) {
-      CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, T, 256, nullptr, 0, ctx->d_tokpe, 256, s));
+      CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, R, 256, nullptr, 0, ctx->d_tokpe, 256, s));
       qin = ctx->d_tokpe;
     }
     {
       SmallLinBatch B;
       B.n = 3;
-      B.d[0] = mk_lin(qin, 256, L.self_attn.q, ctx->d_t1, 256, T, 0);
-      B.d[1] = mk_lin(qin, 256, L.self_attn.k, ctx->d_t2, 256, T, 0);
-      B.d[2] = mk_lin(q, 256, L.self_attn.v, ctx->d_t3, 256, T, 0);
+      B.d[0] = mk_lin(qin, 256, L.self_attn.q, ctx->d_t1, 256, R, 0);
+      B.d[1] = mk_lin(qin, 256, L.self_attn.k, ctx->d_t2, 256, R, 0);
+      B.d[2] = mk_lin(q, 256, L.self_attn.v, ctx->d_t3, 256, R, 0);
       CHK(small_linear_batch_launch(B, s));
     }
-    CHK(small_attn_launch(ctx->d_t1, 256, ctx->d_t2, 256, ctx->d_t3, 256, ctx->d_t4, 256, T, T, 8, 32, 1, 0, 0, 0, s));
-    CHKI(tok_linear(ctx, s, ctx->d_t4, 256, L.self_attn.o, q, 256, T, 0, l > 0 ? q : nullptr, 256));
-    CHKI(tok_ln(ctx, s, q, L.n1, T));
-    DBG_STAGE();   // 0 / 4
+    CHK(small_attn_launch(ctx->d_t1, 256, ctx->d_t2, 256, ctx->d_t3, 256, ctx->d_t4, 256, T, T, 8, 32, N, (size_t)T * 256, (size_t)T * 256,
+                          (size_t)T * 256, s));
+    CHKI(tok_linear(ctx, s, ctx->d_t4, 256, L.self_attn.o, q, 256, R, 0, l > 0 ? q : nullptr, 256));
+    CHKI(tok_ln(ctx, s, q, L.n1, R));
     // ---- tokens attend to the image
-    CHKI(refresh_key_operands(ctx, s, pos_tok));
-    CHKI(t2i_attention(ctx, s, L.t2i_q, L.t2i_k, L.t2i_v, L.t2i_o, T));
-    CHKI(tok_ln(ctx, s, q, L.n2, T));
-    DBG_STAGE();   // 1 / 5
+    CHKI(refresh_key_operands(ctx, s, in.pos_tok, in.pos_shared, N));
+    CHKI(t2i_attention(ctx, s, L.t2i_q, L.t2i_k, L.t2i_v, L.t2i_o, N, T));
+    CHKI(tok_ln(ctx, s, q, L.n2, R));
     // ---- MLP on tokens
-    CHKI(tok_linear(ctx, s, q, 256, L.mlp1, ctx->d_t1, 2048, T, 2));
-    CHKI(tok_linear(ctx, s, ctx->d_t1, 2048, L.mlp2, q, 256, T, 0, q, 256));
-    CHKI(tok_ln(ctx, s, q, L.n3, T));
-    DBG_STAGE();   // 2 / 6
+    CHKI(tok_linear(ctx, s, q, 256, L.mlp1, ctx->d_t1, 2048, R, 2));
+    CHKI(tok_linear(ctx, s, ctx->d_t1, 2048, L.mlp2, q, 256, R, 0, q, 256));
+    CHKI(tok_ln(ctx, s, q, L.n3, R));
     // ---- image attends to the tokens: q = (keys+pe) Wq, k = (tokens+pe) Wk, v = tokens Wv
     {
-      GemmParams p = lin_params(ctx->d_kpe16, 256, 4096, L.i2t_q);
+      GemmParams p = lin_params(ctx->d_kpe16, 256, M, L.i2t_q);
       p.out32 = ctx->d_big1; p.ld32 = 128;
       CHKI(run_gemm(ctx, s, p));
-      CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, T, 256, nullptr, 0, ctx->d_tokpe, 256, s));
+      CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, R, 256, nullptr, 0, ctx->d_tokpe, 256, s));
       {
         SmallLinBatch B;
         B.n = 2;
-        B.d[0] = mk_lin(ctx->d_tokpe, 256, L.i2t_k, ctx->d_t1, 128, T, 0);
-        B.d[1] = mk_lin(q, 256, L.i2t_v, ctx->d_t2, 128, T, 0);
+        B.d[0] = mk_lin(ctx->d_tokpe, 256, L.i2t_k, ctx->d_t1, 128, R, 0);
+        B.d[1] = mk_lin(q, 256, L.i2t_v, ctx->d_t2, 128, R, 0);
         CHK(small_linear_batch_launch(B, s));
       }
-      CHK(small_attn_launch(ctx->d_big1, 128, ctx->d_t1, 128, ctx->d_t2, 128, ctx->d_big2, 128, 4096, T, 8, 16, 1, 0, 0, 0, s));
-      CHK(cast_add_launch(ctx->d_big2, 128, nullptr, 0, 0, 0.f, 4096, 128, ctx->d_big16, 128, nullptr, 0, s));
-      GemmParams o = lin_params(ctx->d_big16, 128, 4096, L.i2t_o);
+      CHK(small_attn_launch(ctx->d_big1, 128, ctx->d_t1, 128, ctx->d_t2, 128, ctx->d_big2, 128, 4096, T, 8, 16, N, (size_t)4096 * 128,
+                            (size_t)T * 128, (size_t)4096 * 128, s));
+      CHK(cast_add_launch(ctx->d_big2, 128, nullptr, 0, 0, 0.f, M, 128, ctx->d_big16, 128, nullptr, 0, s));
+      GemmParams o = lin_params(ctx->d_big16, 128, M, L.i2t_o);
       o.res = ctx->d_keys; o.ldres = 256; o.out32 = ctx->d_keys; o.ld32 = 256;
       CHKI(run_gemm(ctx, s, o));
-      CHK(layernorm_launch(ctx->d_keys, 256, L.n4.w, L.n4.b, 1e-5f, 4096, 256, nullptr, 0, ctx->d_keys, 256, 0, s));
+      CHK(layernorm_launch(ctx->d_keys, 256, L.n4.w, L.n4.b, 1e-5f, M, 256, nullptr, 0, ctx->d_keys, 256, 0, s));
     }
-    DBG_STAGE();   // 3 / 7
   }
   // ---- final token -> image attention + LN (transformer.py:134-139)
-  CHKI(refresh_key_operands(ctx, s, pos_tok));
-  CHKI(t2i_attention(ctx, s, ctx->fin_q, ctx->fin_k, ctx->fin_v, ctx->fin_o, T));
-  CHKI(tok_ln(ctx, s, q, ctx->fin_norm, T));
-  // hs = q: [0] obj score token, [1] iou token, [2..5] mask tokens
-  CHK(hipMemcpyAsync(ctx->d_mtok, q + 2 * 256, (size_t)4 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  CHKI(refresh_key_operands(ctx, s, in.pos_tok, in.pos_shared, N));
+  CHKI(t2i_attention(ctx, s, ctx->fin_q, ctx->fin_k, ctx->fin_v, ctx->fin_o, N, T));
+  CHKI(tok_ln(ctx, s, q, ctx->fin_norm, R));
+  // hs = q: per prompt [0] obj score token, [1] iou token, [2..5] mask tokens
+  CHK(hipMemcpy2DAsync(ctx->d_mtok, (size_t)4 * 256 * sizeof(float), q + 2 * 256, (size_t)T * 256 * sizeof(float), (size_t)4 * 256 * sizeof(float), N,
+                       hipMemcpyDeviceToDevice, s));
   // ---- upscaling: ConvT(256->64) + hr1 -> LN2d -> GELU -> ConvT(64->32) + hr0 -> GELU  (mask_decoder.py:283-288)
   {
-    GemmParams p = lin_params(ctx->d_keys16, 256, 4096, ctx->dc1);
+    GemmParams p = lin_params(ctx->d_keys16, 256, M, ctx->dc1);
     p.out32 = ctx->d_g; p.ld32 = 256;
     CHKI(run_gemm(ctx, s, p));
-    CHK(upscale_glue_launch(ctx->d_g, 64, 64, ctx->dc1_b, hr1_tok, ctx->up_ln.w, ctx->up_ln.b, ctx->d_up1_16, s));
-    GemmParams p2 = lin_params(ctx->d_up1_16, 64, 16384, ctx->dc2);
+    CHK(upscale_glue_launch(ctx->d_g, 64, 64, ctx->dc1_b, in.hr1_tok, ctx->up_ln.w, ctx->up_ln.b, ctx->d_up1_16, N, in.hr1_stride, s));
+    GemmParams p2 = lin_params(ctx->d_up1_16, 64, N * 16384, ctx->dc2);
     p2.out32 = ctx->d_g; p2.ld32 = 128;
     CHKI(run_gemm(ctx, s, p2));
-    CHK(upscale_glue_launch(ctx->d_g, 128, 32, ctx->dc2_b, hr0_tok, nullptr, nullptr, ctx->d_up2_16, s));
+    CHK(upscale_glue_launch(ctx->d_g, 128, 32, ctx->dc2_b, in.hr0_tok, nullptr, nullptr, ctx->d_up2_16, N, in.hr0_stride, s));
   }
-  // ---- hyper-network MLPs on the 4 mask tokens -> [4, 32], IoU head (sigmoid) and object-score head: one launch
+  // ---- hyper-network MLPs on the 4 mask tokens -> [N,4,32], IoU head (sigmoid) and object-score head: one launch
   {
     if (!mlp3_ok(ctx->hyper[0]) || !mlp3_ok(ctx->iou_head) || !mlp3_ok(ctx->obj_head))
       return sam2mi_set_error(ctx, "decoder_forward", "output MLPs must be 256-256-256-n");
     Mlp3Batch B;
     B.n = 6;
-    for (int i = 0; i < 4; ++i) B.g[i] = mk_mlp3(q + (size_t)(2 + i) * 256, ctx->hyper[i], ctx->d_hyper + i * 32, 0);
-    B.g[4] = mk_mlp3(q + 256, ctx->iou_head, ctx->d_iou, 1);
-    B.g[5] = mk_mlp3(q, ctx->obj_head, ctx->d_obj, 0);
+    B.reps = N;
+    for (int i = 0; i < 4; ++i) B.g[i] = mk_mlp3(q + (size_t)(2 + i) * 256, ctx->hyper[i], ctx->d_hyper + i * 32, 0, (long)T * 256, 4 * 32);
+    B.g[4] = mk_mlp3(q + 256, ctx->iou_head, ctx->d_iou, 1, (long)T * 256, 4);
+    B.g[5] = mk_mlp3(q, ctx->obj_head, ctx->d_obj, 0, (long)T * 256, 1);
     CHK(mlp3_launch(B, s));
   }
-  CHK(cast_add_launch(ctx->d_hyper, 32, nullptr, 0, 0, 0.f, 4, 32, ctx->d_hyper16, 32, nullptr, 0, s));
-  // masks[i, pix] = sum_c hyper[i, c] * up[pix, c]   (GEMM over pixels, stored transposed)
-  {
+  CHK(cast_add_launch(ctx->d_hyper, 32, nullptr, 0, 0, 0.f, N * 4, 32, ctx->d_hyper16, 32, nullptr, 0, s));
+  // masks[n, i, pix] = sum_c hyper[n, i, c] * up[n, pix, c]   (GEMM over pixels, stored transposed)
+  for (int n = 0; n < N; ++n) {
     GemmParams p = gemm_params_zero();
-    p.A = ctx->d_up2_16; p.lda = 32; p.W = ctx->d_hyper16; p.ldw = 32; p.M = 65536; p.N = 4; p.K = 32;
-    p.n_split = 0; p.outT32 = ctx->d_masks; p.ldT32 = 65536;
+    p.A = ctx->d_up2_16 + (size_t)n * 65536 * 32; p.lda = 32; p.W = ctx->d_hyper16 + (size_t)n * 4 * 32; p.ldw = 32; p.M = 65536; p.N = 4; p.K = 32;
+    p.n_split = 0; p.outT32 = ctx->d_masks + (size_t)n * 4 * 65536; p.ldT32 = 65536;
     CHKI(run_gemm(ctx, s, p));
   }
   return 0;

@@ -58,9 +58,11 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const SmallLinBatch B
 // each - as separate launches they cost 3 launch latencies apiece, here one launch covers all of them.
 __global__ __launch_bounds__(1024) void mlp3_kernel(const Mlp3Batch B) {
   const Mlp3Group& G = B.g[blockIdx.x];
+  const float* gx = G.x + (size_t)blockIdx.y * G.x_rep_stride;         // blockIdx.y: repetition (one per prompt / object)
+  float* gy = G.y + (size_t)blockIdx.y * G.y_rep_stride;
   __shared__ __attribute__((aligned(16))) float buf[2][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // 16 waves
-  if (tid < 256) buf[0][tid] = G.x[tid];
+  if (tid < 256) buf[0][tid] = gx[tid];
   __syncthreads();
 #pragma unroll 1
   for (int layer = 0; layer < 3; ++layer) {
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(1024) void mlp3_kernel(const Mlp3Batch B) {
         if (lane == 0 && o < N) {
           v += b ? b[o] : 0.f;
           if (layer < 2) buf[(layer + 1) & 1][o] = fmaxf(v, 0.f);
-          else G.y[o] = G.sigmoid_out ? 1.f / (1.f + expf(-v)) : v;
+          else gy[o] = G.sigmoid_out ? 1.f / (1.f + expf(-v)) : v;
         }
       }
     }
@@ -127,8 +129,12 @@ __global__ void dense_pe_kernel(const float* __restrict__ gauss, int S, float* _
 // one wave per output pixel (2Hin x 2Hin grid), C <= 64 channels (lane = channel)
 __global__ __launch_bounds__(256) void upscale_glue_kernel(const float* __restrict__ g, int Hin, int C, const float* __restrict__ bias,
                                                            const float* __restrict__ hr, const float* __restrict__ lnw,
-                                                           const float* __restrict__ lnb, half_t* __restrict__ out16) {
+                                                           const float* __restrict__ lnb, half_t* __restrict__ out16,
+                                                           size_t hr_bstride) {
   const int Hout = 2 * Hin;
+  g += (size_t)blockIdx.y * Hin * Hin * 4 * C;           // batch: contiguous inputs / outputs, hr shared when its stride is 0
+  hr += blockIdx.y * hr_bstride;
+  out16 += (size_t)blockIdx.y * Hout * Hout * C;
   const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (pix >= Hout * Hout) return;
@@ -267,10 +273,10 @@ hipError_t small_linear_launch(const float* x, int ldx, const float* W, const fl
   return small_linear_batch_launch(B, s);
 }
 hipError_t mlp3_launch(const Mlp3Batch& B, hipStream_t s) {
-  if (B.n < 1 || B.n > 8) return hipErrorInvalidValue;
+  if (B.n < 1 || B.n > 8 || B.reps < 1 || B.reps > 65535) return hipErrorInvalidValue;
   for (int i = 0; i < B.n; ++i)
     if (B.g[i].n_out < 1 || B.g[i].n_out > 256) return hipErrorInvalidValue;
-  mlp3_kernel<<<dim3(B.n), dim3(1024), 0, s>>>(B);
+  mlp3_kernel<<<dim3(B.n, B.reps), dim3(1024), 0, s>>>(B);
   return hipGetLastError();
 }
 hipError_t point_embed_launch(const float* pts, const int* labels, int Np, const float* gauss, const float* point_emb4,
@@ -283,10 +289,10 @@ hipError_t dense_pe_launch(const float* gauss, int S, float* out, hipStream_t s)
   return hipGetLastError();
 }
 hipError_t upscale_glue_launch(const float* g, int Hin, int C, const float* bias, const float* hr, const float* lnw,
-                               const float* lnb, half_t* out16, hipStream_t s) {
-  if (C > 64) return hipErrorInvalidValue;
+                               const float* lnb, half_t* out16, int batch, size_t hr_bstride, hipStream_t s) {
+  if (C > 64 || batch < 1 || batch > 65535) return hipErrorInvalidValue;
   const int n = 4 * Hin * Hin;
-  upscale_glue_kernel<<<dim3((n + 3) / 4), dim3(256), 0, s>>>(g, Hin, C, bias, hr, lnw, lnb, out16);
+  upscale_glue_kernel<<<dim3((n + 3) / 4, batch), dim3(256), 0, s>>>(g, Hin, C, bias, hr, lnw, lnb, out16, hr_bstride);
   return hipGetLastError();
 }
 hipError_t select_mask_launch(const float* masks, const float* iou, const float* obj, const float* tokens, int multimask,

@@ -61,8 +61,10 @@ struct SmallLinBatch { SmallLin d[4]; int n; };
 hipError_t small_linear_batch_launch(const SmallLinBatch& B, hipStream_t s);
 // up to 8 fused 3-layer MLPs (256 -> 256 -> 256 -> n_out, ReLU, ReLU, optional sigmoid) on one row each, one launch:
 //   y[0..n_out) = act(W2 relu(W1 relu(W0 x + b0) + b1) + b2);  W row-major [out, 256] f32
-struct Mlp3Group { const float* x; const float* W[3]; const float* b[3]; float* y; int n_out; int sigmoid_out; };
-struct Mlp3Batch { Mlp3Group g[8]; int n; };
+// The launch is repeated `reps` times (grid.y): repetition r reads x + r * x_rep_stride and writes y + r * y_rep_stride
+// (same weights) - one repetition per prompt / object of a batched decoder call.
+struct Mlp3Group { const float* x; const float* W[3]; const float* b[3]; float* y; int n_out; int sigmoid_out; long x_rep_stride; long y_rep_stride; };
+struct Mlp3Batch { Mlp3Group g[8]; int n; int reps; };
 hipError_t mlp3_launch(const Mlp3Batch& B, hipStream_t s);
 // sparse point embeddings (PromptEncoder._embed_points): pts [Np,2] px, labels [Np] -> out [Np+1, 256] (pad point appended)
 hipError_t point_embed_launch(const float* pts, const int* labels, int Np, const float* gauss, const float* point_emb4,
@@ -71,8 +73,9 @@ hipError_t point_embed_launch(const float* pts, const int* labels, int Np, const
 hipError_t dense_pe_launch(const float* gauss, int S, float* out, hipStream_t s);
 // ConvTranspose 2x2 s2 glue.  g [Hin*Hin, 4*C] (GEMM output, column pos*C + c, pos = dy*2+dx) + bias[c] + hr [ (2Hin)^2, C ]
 // -> (LayerNorm2d if lnw) -> GELU -> out16 [(2Hin)^2, C]
+// `batch` images back to back in g / out16; hr advances by hr_bstride floats per image (0: shared)
 hipError_t upscale_glue_launch(const float* g, int Hin, int C, const float* bias, const float* hr, const float* lnw,
-                               const float* lnb, half_t* out16, hipStream_t s);
+                               const float* lnb, half_t* out16, int batch, size_t hr_bstride, hipStream_t s);
 // SAM-head selection on device (SAM2Base._forward_sam_heads :440-484, MaskDecoder.forward :151-169):
 //  masks [4, 65536], iou [4], obj [1], tokens [4,256]  ->  low_sel [65536] (NO_OBJ filled when obj<=0),
 //  tok_sel [256], best_idx [1].  multimask: argmax-IoU over candidates 1..3; otherwise candidate 0 with the

@@ -128,13 +128,7 @@ class SAM2ImagePredictor:
             lab = bl if lab is None else np.concatenate([bl, lab], axis=1)
         if pts is None:
             raise NotImplementedError("prompt-free prediction is not implemented on this backend yet")
-        lows, ious = [], []
-        for b in range(pts.shape[0]):                                  # one decoder pass per prompt (repeat_image)
-            m, s = self.engine.image_predict(slot, pts[b], lab[b], multimask_output)
-            lows.append(m)
-            ious.append(s)
-        low = torch.stack(lows, dim=0)
-        iou = torch.stack(ious, dim=0)
+        low, iou = self.engine.image_predict(slot, pts, lab, multimask_output)      # all prompts in one batched decoder pass
         masks = self.engine.resize_bilinear(low, orig_hw) if tuple(low.shape[-2:]) != tuple(orig_hw) else low
         low = torch.clamp(low, -32.0, 32.0)
         if not return_logits:

@@ -253,12 +253,18 @@ class Engine:
                                                 C.byref(fo)), "sam2mi_video_click")
 
     def image_predict(self, feat_slot: int, coords: np.ndarray, labels: np.ndarray, multimask: bool):
-        coords = np.ascontiguousarray(coords, np.float32).reshape(-1, 2)
-        labels = np.ascontiguousarray(labels, np.int32).reshape(-1)
+        """coords (N, Np, 2) / labels (N, Np): N independent prompts on one image, one batched decoder pass.
+        -> masks (N, 3 or 1, 256, 256), iou (N, 3 or 1)."""
+        coords = np.ascontiguousarray(coords, np.float32)
+        labels = np.ascontiguousarray(labels, np.int32)
+        if coords.ndim == 2:
+            coords, labels = coords[None], labels.reshape(1, -1)
+        N, Np = labels.shape
+        assert coords.shape == (N, Np, 2), (coords.shape, labels.shape)
         c = 3 if multimask else 1
-        masks, iou = self.new(c, 256, 256), self.new(c)
+        masks, iou = self.new(N, c, 256, 256), self.new(N, c)
         self._check(self.lib.sam2mi_image_predict(self.h, self.stream, feat_slot, coords.ctypes.data_as(C.c_void_p),
-                                                  labels.ctypes.data_as(C.c_void_p), len(labels), int(multimask), _ptr(masks), _ptr(iou)),
+                                                  labels.ctypes.data_as(C.c_void_p), N, Np, int(multimask), _ptr(masks), _ptr(iou)),
                     "sam2mi_image_predict")
         return masks, iou
 
