@@ -189,12 +189,15 @@ __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p
 //     values is one contiguous ds_read_b128;
 //   * iteration i runs S_{i+1} = K_{i+1} Q^T beside the exponentials of tile i, then O^T += V_i^T P_i^T;
 //   * the O rescale is deferred to an outer loop (reference maximum raised only past a threshold).
+//   * VALU diet (the d=72 products leave the softmax VALU-bound): the score accumulator starts at -m_ref, so the
+//     probability is exp2 of the MFMA result with no subtraction; and the row sum l = sum_k p comes out of the MFMA too:
+//     "row 72" of the V^T image is a row of ones, so O^T[72][q] accumulates exactly the f16 probabilities the numerator uses.
 // head_dim pad: k-step 4 has only 8 real columns - lanes of the upper half re-read chunk 8 against a zero Q fragment;
-// PV row tile 2 has 8 real rows - the other lanes read row 71 and their products are discarded.
+// PV row tile 2 has 8 real rows + the ones row - the other lanes read the ones row too and their products are discarded.
 constexpr int H2_NST = 4;
 constexpr int H2_KT = 32 * 144;            // 4608 B
 constexpr int H2_VT = HD * 64;             // 4608 B
-constexpr int H2_STAGE = H2_KT + H2_VT;    // 9216 B
+constexpr int H2_STAGE = H2_KT + H2_VT + 64;   // 9280 B: the 64 B behind the V^T image are "row 72" = ones (never touched by the DMA)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnPa
     return k;
   };
   const int vsw = (fr >> 2) & 3;
-  const int v_row2 = min(64 + fr, HD - 1);            // row tile 2: rows past 71 alias row 71 (discarded products)
+  const int v_row2 = min(64 + fr, HD);                // row tile 2: row 72 = the ones row (l accumulates there), rows past it alias it
   const int v_sw2 = (v_row2 >> 2) & 3;
   struct VF { half8 f[6]; };
   auto read_v = [&](int i) {
@@ -277,10 +280,10 @@ __global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnPa
     v.f[5] = *reinterpret_cast<const half8*>(sV + v_row2 * 64 + (((2 + fh) ^ v_sw2) << 4));
     return v;
   };
-  auto qk = [&](const KF& k) {
+  auto qk = [&](const KF& k, float init) {
     f32x16 sa;                     // one chain: a single accumulation chain of this MFMA issues at full rate
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sa[r] = 0.f;
+    for (int r = 0; r < 16; ++r) sa[r] = init;
 #pragma unroll
     for (int ks = 0; ks < 5; ++ks) sa = mfma32(k.f[ks], qf[ks], sa);
     return sa;
@@ -298,7 +301,9 @@ __global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnPa
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   constexpr float RESCALE_THR = 8.f;
-  float m_ref = -1e30f, l_run = 0.f;
+  // ones rows (one per ring stage), before the first barrier
+  for (int j = tid; j < H2_NST * 32; j += 256)
+    *reinterpret_cast<half_t*>(smem + (j >> 5) * H2_STAGE + H2_KT + H2_VT + (j & 31) * 2) = (half_t)1.f;
 
   issue(0);
   if (n > 1) issue(1);
@@ -307,24 +312,30 @@ __global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnPa
   else if (n > 1) h2_wait_vm<3>();
   else h2_wait_vm<0>();
   __builtin_amdgcn_s_barrier();
+  // scores are kept RELATIVE to the reference maximum: s' = s - m_ref (first tile: subtract its own row maximum)
   f32x16 s;
+  float m_ref;
   {
     const KF k0 = read_k(0);
     __builtin_amdgcn_sched_barrier(0);
-    s = qk(k0);
+    s = qk(k0, 0.f);
+    m_ref = rowmax(s);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] -= m_ref;
   }
-  float tmax = rowmax(s);
+  float tmax = 0.f;                                      // row maximum of s', relative to m_ref
   int i = 0;
   for (;;) {
-    {                                                    // raise the reference maximum (first entry: from -1e30, O = 0)
-      const float m_new = fmaxf(m_ref, tmax);
-      const float alpha = __builtin_amdgcn_exp2f(m_ref - m_new);
-      l_run *= alpha;
+    {                                                    // raise the reference maximum by the excess (first entry: 0)
+      const float delta = fmaxf(tmax, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-      m_ref = m_new;
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;    // row 72 of tile 2 is l: rescaled with the rest
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] -= delta;
+      m_ref += delta;
     }
     bool done = false;
 #pragma nounroll
@@ -337,17 +348,10 @@ __global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnPa
       const KF kn = read_k(i + 1);                       // past the last tile: stale ring data, result unused
       const VF vf = read_v(i);
       __builtin_amdgcn_sched_barrier(0);
-      const f32x16 s_next = qk(kn);
-      float psum = 0.f;
+      const f32x16 s_next = qk(kn, -m_ref);
       half8 pf[2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(s[r] - m_ref);
-        psum += pv;
-        pf[r >> 3][r & 7] = (half_t)pv;
-      }
-      psum += __shfl_xor(psum, 32, 64);
-      l_run += psum;
+      for (int r = 0; r < 16; ++r) pf[r >> 3][r & 7] = (half_t)__builtin_amdgcn_exp2f(s[r]);
 #pragma unroll
       for (int t = 0; t < 3; ++t) o[t] = mfma32(vf.f[2 * t], pf[0], o[t]);
 #pragma unroll
@@ -356,11 +360,13 @@ __global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnPa
       tmax = rowmax(s);
       ++i;
       if (i >= n) { done = true; break; }
-      if (__any(tmax > m_ref + RESCALE_THR)) break;
+      if (__any(tmax > RESCALE_THR)) break;
     }
     if (done) break;
   }
 
+  // l = O^T[72][q]: accumulator row 8 of row tile 2 = register 4 of the lower lane half
+  const float l_run = __shfl(o[2][4], fr, 64);
   const float inv = 1.f / l_run;
   half_t* orow = p.o + qrow * p.ldo + head * HD;
 #pragma unroll
