@@ -127,7 +127,14 @@ typedef struct sam2mi_frame_out {
 /* Conditioning frame with point prompts (add_new_points_or_box -> track_step, is_init_cond_frame):
  * SAM heads on feat + no_mem_embed; stores obj_ptr / score / low-res mask in bank slot `bank_slot`. */
 int sam2mi_video_click(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int Np,
+                       const float* mask_logits /* device [256*256] previous low-res logits as dense prompt, or NULL */,
                        int multimask, int bank_slot, const sam2mi_frame_out* out);
+
+/* Mask prompt on a frame (add_new_mask -> track_step with mask_inputs -> SAM2Base._use_mask_as_output,
+ * sam2_base_official.py:496-546): the binary mask IS the output - low-res logits = antialiased 4x down-sampling of
+ * mask*20-10, object score +-10 by "any pixel set" - and the SAM decoder, fed mask_downsample(mask) as dense prompt on the raw
+ * frame features, only supplies the object pointer.  mask1024: device {0,1} float [image_size^2]. */
+int sam2mi_video_mask(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* mask1024, int bank_slot, const sam2mi_frame_out* out);
 
 /* Hole filling (fill_holes_in_mask_scores, utils/misc.py:312-338; replaces the reference's CUDA extension
  * csrc/connected_components.cu:62-282, bound at utils/misc.py:59-62): background (score <= 0) 8-connected components
@@ -143,9 +150,20 @@ int sam2mi_set_fill_hole_area(sam2mi_ctx* ctx, int max_area);
  * mask and object score stored in the slot, writes the bf16-rounded memory features into the slot. */
 int sam2mi_video_encode_memory(sam2mi_ctx* ctx, void* stream, int feat_slot, int bank_slot, int is_mask_from_pts);
 
-/* Tracked frame: memory attention over `sel`, SAM heads (multimask), memory encoder; result in `bank_slot`. */
-int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, const sam2mi_mem_select* sel, int bank_slot,
-                       int run_mem_encoder, const sam2mi_frame_out* out);
+/* Prompt on a tracked frame (correction clicks: add_new_points_or_box on a frame that already has memories,
+ * sam2_video_predictor_official.py:337-366 -> track_step :1136-1142). */
+typedef struct sam2mi_prompt {
+  const float* coords;        /* [num_points,2] pixels at image_size (host or device memory) */
+  const int32_t* labels;      /* [num_points] */
+  int32_t num_points;
+  int32_t multimask;          /* 1: 3 candidates, best by IoU; 0: one mask with the dynamic stability fallback */
+  const float* mask_logits;   /* device [256*256]: previous low-res logits (clamped to +-32 by the caller) as dense prompt, or NULL */
+} sam2mi_prompt;
+
+/* Tracked frame: memory attention over `sel`, SAM heads, memory encoder; result in `bank_slot`.
+ * prompt == NULL: plain propagation (no prompt, multimask).  Otherwise the user's points / previous mask are the prompt. */
+int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, const sam2mi_mem_select* sel, const sam2mi_prompt* prompt,
+                       int bank_slot, int run_mem_encoder, const sam2mi_frame_out* out);
 
 /* Image predictor: prompt encoder + mask decoder on a cached frame (SAM2ImagePredictor._predict,
  * sam2_image_predictor.py:487-589: features + no_mem_embed, no object-score gating).  N independent prompts of Np points each

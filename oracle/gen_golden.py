@@ -2,7 +2,7 @@
 from /root/reference on seeded synthetic inputs and weights.  Container-only; the
 outputs (data, not code) are committed and travel to the GPU box.
 
-    python -m oracle.gen_golden [plugs] [video] [tiny]
+    python -m oracle.gen_golden [plugs] [video] [tiny] [interact]
 
 Weights: sam2_opt_amd.weights.synthetic_state_dict(cfg, seed=0)   (regenerated anywhere)
 Inputs : sam2_opt_amd.synthetic.*  with the seeds named below.
@@ -152,6 +152,52 @@ def gen_video():
     print("video done", time.time() - t0)
 
 
+INTERACT_FRAMES = 6
+
+
+def interact_mask():
+    """The synthetic mask prompt of the interactive scenario: a disc + a bar, at video resolution (1024^2)."""
+    yy, xx = np.mgrid[0:1024, 0:1024]
+    return ((yy - 470) ** 2 + (xx - 540) ** 2 < 180 ** 2) | ((abs(yy - 800) < 40) & (abs(xx - 300) < 160))
+
+
+@torch.inference_mode()
+def gen_interact():
+    """Mask prompt + correction click (SAM2VideoPredictor.add_new_mask, add_new_points_or_box on a tracked frame):
+    mask on frame 0 -> propagate 6 frames -> negative click on tracked frame 3 -> propagate frames 4.. again."""
+    cfg = get_config("large")
+    sd = synthetic_state_dict(cfg, seed=0)
+    model = build_reference_model(cfg, "video", sd, fill_hole_area=0)
+    frames = normalize_frames(synthetic_frames_u8(seed=4, num_frames=INTERACT_FRAMES), cfg)
+    import sam2.sam2_video_predictor_official as vp
+    vp.load_video_frames = lambda **kw: (frames, 1024, 1024)
+    store = {}
+    t0 = time.time()
+    state = model.init_state(video_path="synthetic")
+    _, _, vm = model.add_new_mask(state, frame_idx=0, obj_id=1, mask=interact_mask())
+    pack(store, "mask0/video_res_mask", vm, 16384)
+    cur = state["temp_output_dict_per_obj"][0]["cond_frame_outputs"][0]
+    pack(store, "mask0/pred_masks", cur["pred_masks"], 16384)
+    pack(store, "mask0/obj_ptr", cur["obj_ptr"], 256)
+    pack(store, "mask0/object_score_logits", cur["object_score_logits"], 1)
+    for fi, ids, vm in model.propagate_in_video(state):
+        pack(store, f"p1/f{fi}/video_res_mask", vm, 8192)
+        print("pass 1 frame", fi, time.time() - t0, flush=True)
+    _, _, vm = model.add_new_points_or_box(state, frame_idx=3, obj_id=1, points=np.array([[600.0, 400.0]], np.float32),
+                                           labels=np.array([0], np.int32))
+    pack(store, "fix3/video_res_mask", vm, 16384)
+    cur = state["temp_output_dict_per_obj"][0]["non_cond_frame_outputs"][3]
+    pack(store, "fix3/obj_ptr", cur["obj_ptr"], 256)
+    pack(store, "fix3/object_score_logits", cur["object_score_logits"], 1)
+    # a corrected non-conditioning frame is re-tracked (and its correction lost) when propagation passes over it
+    # (add_all_frames_to_correct_as_cond=False): continue from the frame after it, which sees the corrected memory
+    for fi, ids, vm in model.propagate_in_video(state, start_frame_idx=4):
+        pack(store, f"p2/f{fi}/video_res_mask", vm, 8192)
+        print("pass 2 frame", fi, time.time() - t0, flush=True)
+    np.savez_compressed(os.path.join(GOLD, "large_interact6.npz"), **store)
+    print("interact done", time.time() - t0)
+
+
 @torch.inference_mode()
 def gen_tiny():
     """BASELINE.json configs[0]: SAM2.1-hiera-tiny image predictor, one 1024^2 frame, torch backend on the CPU - the
@@ -185,3 +231,5 @@ if __name__ == "__main__":
         gen_video()
     if "tiny" in which:
         gen_tiny()
+    if "interact" in which:
+        gen_interact()

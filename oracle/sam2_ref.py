@@ -433,6 +433,22 @@ def sam_heads(pix_feat, hr0, hr1, sd, cfg, points=None, labels=None, mask_input=
                 high_res_masks=high, obj_ptr=ptr, object_score_logits=obj)
 
 
+def use_mask_as_output(pix_feat_raw, hr0, hr1, mask_inputs, sd, cfg):
+    """SAM2Base._use_mask_as_output (modeling/sam2_base_official.py:496-546): a binary mask input (B,1,S,S) becomes the
+    output as it is; the SAM heads (on the raw frame features, with mask_downsample(mask) as dense prompt) only supply
+    the object pointer."""
+    m = mask_inputs.float()
+    high = m * 20.0 - 10.0
+    low = F.interpolate(high, size=(high.shape[-2] // 4, high.shape[-1] // 4), align_corners=False, mode="bilinear", antialias=True)
+    md = F.conv2d(m, sd["mask_downsample.weight"], sd["mask_downsample.bias"], stride=4)
+    ptr = sam_heads(pix_feat_raw, hr0, hr1, sd, cfg, None, None, md, False)["obj_ptr"]
+    lam = torch.any(m.flatten(1) > 0.0, dim=1)[..., None].float()
+    obj = 20.0 * lam - 10.0
+    ptr = lam * ptr + (1 - lam) * sd["no_obj_ptr"]
+    return dict(low_res_multimasks=low, high_res_multimasks=high, ious=torch.ones(m.shape[0], 1), low_res_masks=low,
+                high_res_masks=high, obj_ptr=ptr, object_score_logits=obj)
+
+
 # ----------------------------------------------------------------------------- memory encoder (a16)
 def memory_encoder(pix_feat, masks, sd, cfg):
     """MemoryEncoder.inference_memory_torch (modeling/memory_encoder.py:233-241) with
@@ -518,8 +534,8 @@ def assemble_memory(frame_idx, cond_outputs, non_cond_outputs, num_frames, sd, c
 
 # ----------------------------------------------------------------------------- video predictor (a17)
 class VideoOracle:
-    """Single-object forward propagation exactly as SAM2VideoPredictor does it
-    (sam2_video_predictor_official.py: init_state :147-205, add_new_points_or_box :266-399,
+    """Single-object propagation exactly as SAM2VideoPredictor does it
+    (sam2_video_predictor_official.py: init_state :147-205, add_new_points_or_box :266-399, add_new_mask :403-489,
     propagate_in_video_preflight :585-649, propagate_in_video :651-736,
     _run_single_frame_inference :843-909) with fill_hole_area=0 (what the reference does on
     a box without its CUDA extension, utils/misc.py:321-336)."""
@@ -530,6 +546,9 @@ class VideoOracle:
         self.num_frames = frames.shape[0]
         self.video_hw = video_hw or (cfg["image_size"], cfg["image_size"])
         self.cond, self.non_cond = OrderedDict(), OrderedDict()
+        self.temp = {"cond": OrderedDict(), "non_cond": OrderedDict()}      # interacted frames not yet consolidated
+        self.tracked = {}                         # frame -> reverse flag
+        self.points = {}                          # frame -> (pts, lab) accumulated clicks
         self._feat_cache = {}
         self.trace = {}                           # per-frame debug tensors for parity tests
 
@@ -544,36 +563,7 @@ class VideoOracle:
             return low
         return F.interpolate(low, size=(H, W), mode="bilinear", align_corners=False)
 
-    def add_new_points(self, frame_idx, points, labels, normalize_coords=True):
-        cfg, sd = self.cfg, self.sd
-        pts = torch.as_tensor(points, dtype=torch.float32).reshape(1, -1, 2)
-        lab = torch.as_tensor(labels, dtype=torch.int32).reshape(1, -1)
-        if normalize_coords:
-            pts = pts / torch.tensor([self.video_hw[1], self.video_hw[0]], dtype=torch.float32)
-        pts = pts * cfg["image_size"]
-        f = self._features(frame_idx)
-        pix = f[6] + sd["no_mem_embed"].view(1, -1, 1, 1)      # directly_add_no_mem_embed (:953-957)
-        n = lab.shape[1]
-        multimask = cfg["multimask_min_pt_num"] <= n <= cfg["multimask_max_pt_num"]
-        out = sam_heads(pix, f[4], f[5], sd, cfg, pts, lab, None, multimask)
-        cur = dict(pred_masks=out["low_res_masks"], obj_ptr=out["obj_ptr"],
-                   object_score_logits=out["object_score_logits"], maskmem_features=None,
-                   maskmem_pos_enc=None, is_pts=True)
-        self.cond[frame_idx] = cur
-        self.trace[("click", frame_idx)] = out
-        return self._video_res(out["low_res_masks"])
-
-    def _preflight(self):
-        for t, out in self.cond.items():
-            if out["maskmem_features"] is None:
-                hi = F.interpolate(out["pred_masks"], size=(self.cfg["image_size"],) * 2, mode="bilinear",
-                                   align_corners=False)
-                f = self._features(t)
-                feats, pos = encode_new_memory(f[6], hi, out["object_score_logits"], True, self.sd, self.cfg)
-                out["maskmem_features"] = feats.to(torch.bfloat16)
-                out["maskmem_pos_enc"] = pos
-
-    def track_frame(self, t):
+    def _memory_conditioned(self, t):
         cfg, sd = self.cfg, self.sd
         f = self._features(t)
         S = f[6].shape[-1]
@@ -581,25 +571,90 @@ class VideoOracle:
         curr_pos = f[3].flatten(2).permute(2, 0, 1)
         mem, mpos, ex, expos = assemble_memory(t, self.cond, self.non_cond, self.num_frames, sd, cfg)
         pix = memory_attention(curr, mem, curr_pos, mpos, ex, expos, sd, cfg)
-        pix = pix.permute(1, 2, 0).view(1, cfg["d_model"], S, S)
+        return pix.permute(1, 2, 0).view(1, cfg["d_model"], S, S), (curr, mem, curr_pos, mpos, ex, expos)
+
+    def add_new_points(self, frame_idx, points, labels, normalize_coords=True, clear_old_points=True):
+        cfg, sd = self.cfg, self.sd
+        pts = torch.as_tensor(points, dtype=torch.float32).reshape(1, -1, 2)
+        lab = torch.as_tensor(labels, dtype=torch.int32).reshape(1, -1)
+        if normalize_coords:
+            pts = pts / torch.tensor([self.video_hw[1], self.video_hw[0]], dtype=torch.float32)
+        pts = pts * cfg["image_size"]
+        if not clear_old_points and frame_idx in self.points:
+            pts = torch.cat([self.points[frame_idx][0], pts], dim=1)
+            lab = torch.cat([self.points[frame_idx][1], lab], dim=1)
+        self.points[frame_idx] = (pts, lab)
+        is_init = frame_idx not in self.tracked
+        key = "cond" if is_init else "non_cond"
+        prev = self.temp[key].get(frame_idx) or self.cond.get(frame_idx) or self.non_cond.get(frame_idx)
+        prev_logits = torch.clamp(prev["pred_masks"], -32.0, 32.0) if prev is not None else None      # :352-366
+        f = self._features(frame_idx)
+        if is_init:
+            pix = f[6] + sd["no_mem_embed"].view(1, -1, 1, 1)      # directly_add_no_mem_embed (:953-957)
+        else:
+            pix, _ = self._memory_conditioned(frame_idx)             # correction clicks on a tracked frame
+        n = lab.shape[1]
+        multimask = cfg["multimask_min_pt_num"] <= n <= cfg["multimask_max_pt_num"]
+        out = sam_heads(pix, f[4], f[5], sd, cfg, pts, lab, prev_logits, multimask)
+        self.temp[key][frame_idx] = dict(pred_masks=out["low_res_masks"], obj_ptr=out["obj_ptr"],
+                                         object_score_logits=out["object_score_logits"], maskmem_features=None,
+                                         maskmem_pos_enc=None, is_pts=True)
+        self.trace[("click", frame_idx)] = out
+        return self._video_res(out["low_res_masks"])
+
+    def add_new_mask(self, frame_idx, mask):
+        """mask: bool/float (H, W); resized like the reference (:421-434) when it is not image_size^2."""
+        cfg, sd = self.cfg, self.sd
+        m = torch.as_tensor(mask).float()[None, None]
+        S = cfg["image_size"]
+        if m.shape[-2:] != (S, S):
+            m = (F.interpolate(m, size=(S, S), align_corners=False, mode="bilinear", antialias=True) >= 0.5).float()
+        self.points.pop(frame_idx, None)
+        key = "cond" if frame_idx not in self.tracked else "non_cond"
+        f = self._features(frame_idx)
+        out = use_mask_as_output(f[6], f[4], f[5], m, sd, cfg)        # raw features: no memory, no no_mem_embed (:1120-1131)
+        self.temp[key][frame_idx] = dict(pred_masks=out["low_res_masks"], obj_ptr=out["obj_ptr"],
+                                         object_score_logits=out["object_score_logits"], maskmem_features=None,
+                                         maskmem_pos_enc=None, is_pts=False)
+        self.trace[("mask", frame_idx)] = out
+        return self._video_res(out["low_res_masks"])
+
+    def _preflight(self):
+        """propagate_in_video_preflight: interacted frames get their memory (binarised mask) and move to the output dicts."""
+        for key, dst in (("non_cond", self.non_cond), ("cond", self.cond)):
+            for t, out in self.temp[key].items():
+                hi = F.interpolate(out["pred_masks"], size=(self.cfg["image_size"],) * 2, mode="bilinear", align_corners=False)
+                f = self._features(t)
+                feats, pos = encode_new_memory(f[6], hi, out["object_score_logits"], True, self.sd, self.cfg)
+                out["maskmem_features"] = feats.to(torch.bfloat16)
+                out["maskmem_pos_enc"] = pos
+                dst[t] = out
+            self.temp[key].clear()
+        for t in self.cond:
+            self.non_cond.pop(t, None)
+
+    def track_frame(self, t):
+        cfg, sd = self.cfg, self.sd
+        f = self._features(t)
+        pix, memattn_in = self._memory_conditioned(t)
         out = sam_heads(pix, f[4], f[5], sd, cfg, None, None, None, True)   # multimask for tracking
         feats, pos = encode_new_memory(f[6], out["high_res_masks"], out["object_score_logits"], False, sd, cfg)
         self.non_cond[t] = dict(pred_masks=out["low_res_masks"], obj_ptr=out["obj_ptr"],
                                 object_score_logits=out["object_score_logits"],
                                 maskmem_features=feats.to(torch.bfloat16), maskmem_pos_enc=pos)
-        self.trace[("track", t)] = dict(out, memattn_in=(curr, mem, curr_pos, mpos, ex, expos), pix_feat=pix,
-                                        maskmem_features=feats)
+        self.trace[("track", t)] = dict(out, memattn_in=memattn_in, pix_feat=pix, maskmem_features=feats)
         return out["low_res_masks"]
 
-    def propagate(self, max_frames=None):
+    def propagate(self, max_frames=None, start_frame_idx=None):
         self._preflight()
-        start = min(self.cond)
+        start = min(self.cond) if start_frame_idx is None else start_frame_idx
         end = self.num_frames - 1 if max_frames is None else min(start + max_frames, self.num_frames - 1)
         for t in range(start, end + 1):
             if t in self.cond:
                 low = self.cond[t]["pred_masks"]
             else:
                 low = self.track_frame(t)
+            self.tracked[t] = False
             yield t, self._video_res(low)
 
 

@@ -148,6 +148,13 @@ struct sam2mi_ctx {
   half_t* d_up1_16 = nullptr; half_t* d_up2_16 = nullptr; float* d_g = nullptr;
   float* d_hyper = nullptr; half_t* d_hyper16 = nullptr;
   float* d_fill_tmp = nullptr;     // [65536] hole-filling scratch
+  // mask prompts (add_new_mask / correction clicks)
+  MaskEmbedW mask_embed{};         // sam_prompt_encoder.mask_downscaling.{0,1,3,4,6}
+  float* mds_w = nullptr; float* mds_b = nullptr;     // SAM2Base.mask_downsample (Conv2d 1->1, k4 s4)
+  float* d_mask256 = nullptr;      // [65536] mask prompt at the prompt encoder's input size
+  float* d_dense = nullptr;        // [4096,256] dense prompt embedding of a mask prompt
+  float* d_pm10 = nullptr;         // [2]: {+10 / -10 object score of a mask input, scratch}
+  int* d_flag = nullptr;
   int fill_hole_area = 0;          // sam2mi_set_fill_hole_area: 0 = off (SAM2Base.fill_hole_area, build_sam.py:129)
   float* d_masks = nullptr; float* d_iou = nullptr; float* d_obj = nullptr; float* d_mtok = nullptr;
   float* d_low_multi = nullptr; float* d_low_sel = nullptr; float* d_tok_sel = nullptr; int* d_best = nullptr; float* d_iou_sel = nullptr;

@@ -268,9 +268,15 @@ static int build_tokens(sam2mi_ctx* ctx, hipStream_t s, const float* coords, con
 static DecoderIn one_image_in(sam2mi_ctx* ctx, const sam2mi_ctx::FeatSlot& f) {
   return DecoderIn{ctx->t_pix, 0, ctx->no_mask_embed, 1, 0, ctx->dense_pe, true, ctx->d_sparse, f.fpn0, 0, f.fpn1, 0};
 }
+// same with a mask prompt: the dense embedding is PromptEncoder._embed_masks(mask256) instead of no_mask_embed
+static int one_image_in_mask(sam2mi_ctx* ctx, hipStream_t s, const sam2mi_ctx::FeatSlot& f, const float* keys, const float* mask256, DecoderIn& in) {
+  CHK(mask_embed_launch(mask256, ctx->mask_embed, ctx->d_dense, s));
+  in = DecoderIn{keys, 0, ctx->d_dense, 4096, 0, ctx->dense_pe, true, ctx->d_sparse, f.fpn0, 0, f.fpn1, 0};
+  return 0;
+}
 
 extern "C" int sam2mi_video_click(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int Np,
-                                  int multimask, int bank_slot, const sam2mi_frame_out* out) {
+                                  const float* mask_logits, int multimask, int bank_slot, const sam2mi_frame_out* out) {
   REQUIRE_READY();
   hipStream_t s = S(stream);
   if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size() || bank_slot < 0 || bank_slot >= (int)ctx->bank.size())
@@ -280,9 +286,51 @@ extern "C" int sam2mi_video_click(sam2mi_ctx* ctx, void* stream, int feat_slot, 
   CHK(cast_add_launch(f.feat2, 256, ctx->no_mem_embed, 256, 1, 1.f, 4096, 256, nullptr, 0, ctx->t_pix, 256, s));
   int T = 0;
   CHKI(build_tokens(ctx, s, coords, labels, 1, Np, T));
-  CHKI(decoder_forward(ctx, s, one_image_in(ctx, f), 1, T));
+  DecoderIn in = one_image_in(ctx, f);
+  if (mask_logits) CHKI(one_image_in_mask(ctx, s, f, ctx->t_pix, mask_logits, in));     // previous mask logits as dense prompt (:1136-1142)
+  CHKI(decoder_forward(ctx, s, in, 1, T));
   if (out && out->pix_feat) CHK(hipMemcpyAsync(out->pix_feat, ctx->t_pix, (size_t)4096 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
   return sam_heads_finish(ctx, s, multimask, bank_slot, out);
+}
+
+// SAM2Base._use_mask_as_output (sam2_base_official.py:496-546): a binary mask input IS the output; the SAM decoder only
+// supplies the object pointer.  mask1024: {0,1} float [image_size^2] (already resized / thresholded like
+// sam2_video_predictor_official.py add_new_mask).  Stores low-res logits, pointer and +-10 score in `bank_slot`.
+extern "C" int sam2mi_video_mask(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* mask1024, int bank_slot, const sam2mi_frame_out* out) {
+  REQUIRE_READY();
+  hipStream_t s = S(stream);
+  if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size() || bank_slot < 0 || bank_slot >= (int)ctx->bank.size())
+    return sam2mi_set_error(ctx, __func__, "slot out of range");
+  if (!mask1024) return sam2mi_set_error(ctx, __func__, "null mask");
+  const sam2mi_ctx::FeatSlot& f = ctx->feats[feat_slot];
+  sam2mi_ctx::BankSlot& bk = ctx->bank[bank_slot];
+  const int S1 = ctx->cfg.image_size;
+  // object pointer: SAM heads on the RAW frame features (track_step :1120-1131) with mask_downsample(mask) as dense prompt, no points
+  CHK(conv4x4s4_launch(mask1024, S1, ctx->mds_w, ctx->mds_b, ctx->d_mask256, ctx->d_flag, s));
+  int T = 0;
+  CHKI(build_tokens(ctx, s, nullptr, nullptr, 1, 0, T));
+  CHK(hipMemcpyAsync(ctx->d_sparse + (size_t)T * 256, ctx->d_sparse + (size_t)(T - 1) * 256, 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  T += 1;
+  DecoderIn in;
+  CHKI(one_image_in_mask(ctx, s, f, f.feat2, ctx->d_mask256, in));
+  CHKI(decoder_forward(ctx, s, in, 1, T));
+  CHKI(sam_heads_finish(ctx, s, 0, bank_slot, nullptr));           // single-mask path: token 0 -> obj_ptr, gated by the decoder's score
+  // the mask decides whether the object is there (:527-535): score = +-10, pointer gated once more
+  CHK(flag_to_score_launch(ctx->d_flag, 10.f, -10.f, ctx->d_pm10, s));
+  CHK(gate_obj_ptr_launch(bk.obj_ptr, ctx->no_obj_ptr, ctx->d_pm10, 256, s));
+  CHK(hipMemcpyAsync(bk.obj_score, ctx->d_pm10, sizeof(float), hipMemcpyDeviceToDevice, s));
+  // low-res output = antialiased 4x down-sampling of mask * 20 - 10 (:503-511)
+  CHK(aa_down4_launch(mask1024, S1, 20.f, -10.f, bk.low_mask, s));
+  if (ctx->fill_hole_area > 0) {
+    CHK(fill_holes_launch(bk.low_mask, ctx->d_fill_tmp, 1, 256, 256, ctx->fill_hole_area, s));
+    CHK(hipMemcpyAsync(bk.low_mask, ctx->d_fill_tmp, 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  if (out) {
+    if (out->low_res_masks) CHK(hipMemcpyAsync(out->low_res_masks, bk.low_mask, 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out->obj_ptr) CHK(hipMemcpyAsync(out->obj_ptr, bk.obj_ptr, 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out->object_score_logits) CHK(hipMemcpyAsync(out->object_score_logits, ctx->d_pm10, sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  return 0;
 }
 
 extern "C" int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int N, int Np,
@@ -334,8 +382,8 @@ extern "C" int sam2mi_video_encode_memory(sam2mi_ctx* ctx, void* stream, int fea
   return 0;
 }
 
-extern "C" int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, const sam2mi_mem_select* sel, int bank_slot,
-                                  int run_mem_encoder, const sam2mi_frame_out* out) {
+extern "C" int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, const sam2mi_mem_select* sel, const sam2mi_prompt* prompt,
+                                  int bank_slot, int run_mem_encoder, const sam2mi_frame_out* out) {
   REQUIRE_READY();
   hipStream_t s = S(stream);
   if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size() || bank_slot < 0 || bank_slot >= (int)ctx->bank.size())
@@ -374,11 +422,19 @@ extern "C" int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, 
   CHKI(memattn_forward(ctx, s, f.feat2, ctx->sine_pe_tok64, L * 4096 + P, L * 4096, ctx->t_pix));
   if (out && out->pix_feat) CHK(hipMemcpyAsync(out->pix_feat, ctx->t_pix, (size_t)4096 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
   int T = 0;
-  CHKI(build_tokens(ctx, s, nullptr, nullptr, 1, 0, T));      // no prompt: one padding point (label -1) + pad
-  // _forward_sam_heads pads with ONE (0,0)/-1 point and the prompt encoder appends another pad point (:395-401, prompt_encoder.py:133-137)
-  CHK(hipMemcpyAsync(ctx->d_sparse + (size_t)T * 256, ctx->d_sparse + (size_t)(T - 1) * 256, 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  T += 1;
-  CHKI(decoder_forward(ctx, s, one_image_in(ctx, f), 1, T));
-  CHKI(sam_heads_finish(ctx, s, 1, bank_slot, out, run_mem_encoder ? feat_slot : -1));
+  const bool has_pts = prompt && prompt->num_points > 0;
+  if (has_pts) {
+    // correction clicks on a tracked frame: memory-conditioned features + the user's points (+ previous mask logits)
+    CHKI(build_tokens(ctx, s, prompt->coords, prompt->labels, 1, prompt->num_points, T));
+  } else {
+    CHKI(build_tokens(ctx, s, nullptr, nullptr, 1, 0, T));      // no prompt: one padding point (label -1) + pad
+    // _forward_sam_heads pads with ONE (0,0)/-1 point and the prompt encoder appends another pad point (:395-401, prompt_encoder.py:133-137)
+    CHK(hipMemcpyAsync(ctx->d_sparse + (size_t)T * 256, ctx->d_sparse + (size_t)(T - 1) * 256, 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    T += 1;
+  }
+  DecoderIn in = one_image_in(ctx, f);
+  if (prompt && prompt->mask_logits) CHKI(one_image_in_mask(ctx, s, f, ctx->t_pix, prompt->mask_logits, in));
+  CHKI(decoder_forward(ctx, s, in, 1, T));
+  CHKI(sam_heads_finish(ctx, s, prompt ? prompt->multimask : 1, bank_slot, out, run_mem_encoder ? feat_slot : -1));
   return 0;
 }

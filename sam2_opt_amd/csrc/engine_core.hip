@@ -526,6 +526,13 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
     }
     ctx->not_a_point = pk.f32(pe + "not_a_point_embed.weight");
     ctx->no_mask_embed = pk.f32(pe + "no_mask_embed.weight");
+    ctx->mask_embed = MaskEmbedW{pk.f32(pe + "mask_downscaling.0.weight"), pk.f32(pe + "mask_downscaling.0.bias"),
+                                 pk.f32(pe + "mask_downscaling.1.weight"), pk.f32(pe + "mask_downscaling.1.bias"),
+                                 pk.f32(pe + "mask_downscaling.3.weight"), pk.f32(pe + "mask_downscaling.3.bias"),
+                                 pk.f32(pe + "mask_downscaling.4.weight"), pk.f32(pe + "mask_downscaling.4.bias"),
+                                 pk.f32(pe + "mask_downscaling.6.weight"), pk.f32(pe + "mask_downscaling.6.bias")};
+    ctx->mds_w = pk.f32("mask_downsample.weight");
+    ctx->mds_b = pk.f32("mask_downsample.bias");
   }
 
   // ---- memory encoder
@@ -627,6 +634,10 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ALLOC(ctx->t_vTall16, half_t, (size_t)1024 * NKCAP);
   ALLOC(ctx->t_opart, float, (size_t)16 * 4096 * 256);
   ALLOC(ctx->d_fill_tmp, float, (size_t)65536);
+  ALLOC(ctx->d_mask256, float, (size_t)65536);
+  ALLOC(ctx->d_dense, float, (size_t)4096 * 256);
+  ALLOC(ctx->d_pm10, float, 2);
+  ALLOC(ctx->d_flag, int, 2);
   ALLOC(ctx->t_ml, float, (size_t)16 * 4096 * 2);
   ALLOC(ctx->t_ptr_tok, float, 128 * 64);
   ALLOC(ctx->t_ptr_pos, float, 128 * 64);

@@ -48,6 +48,14 @@ hipError_t dwconv7_launch(const float* in, int H, int C, const float* w, const f
 constexpr int FILL_HOLES_MAX_AREA = 63;      // visited list of max_area + 1 ints per thread in LDS (64 KiB per workgroup)
 hipError_t fill_holes_launch(const float* in, float* out, int N, int H, int W, int max_area, hipStream_t s);
 
+// mask prompts: antialiased 4x bilinear down-sampling of in * a + b ([S,S] -> [S/4,S/4]); SAM2Base.mask_downsample (4x4 s4 conv,
+// also sets *any_pos when a pixel is > 0); PromptEncoder._embed_masks on a [256,256] prompt -> dense [4096,256] token-major
+struct MaskEmbedW { const float *w1, *b1, *ln1w, *ln1b, *w2, *b2, *ln2w, *ln2b, *w3, *b3; };
+hipError_t aa_down4_launch(const float* in, int S, float a, float b, float* out, hipStream_t s);
+hipError_t conv4x4s4_launch(const float* in, int S, const float* w, const float* bias, float* out, int* any_pos, hipStream_t s);
+hipError_t mask_embed_launch(const float* mask256, const MaskEmbedW& W, float* dense_tok, hipStream_t s);
+hipError_t flag_to_score_launch(const int* flag, float on, float off, float* out, hipStream_t s);   // out[0] = flag ? on : off
+
 // ---------------------------------------------------------------- heads.hip (prompt encoder, mask decoder glue)
 // y[t, n] = act(sum_k x[t, k] W[n, k] + b[n]) (+ res[t, n]);  f32 everywhere, T <= 64.  act: 0 none, 2 relu, 3 sigmoid
 hipError_t small_linear_launch(const float* x, int ldx, const float* W, const float* b, float* y, int ldy,

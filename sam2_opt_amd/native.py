@@ -18,7 +18,7 @@ EXPORTS = [
     "sam2mi_abi_version", "sam2mi_create", "sam2mi_destroy", "sam2mi_last_error", "sam2mi_load_weight",
     "sam2mi_finalize_weights", "sam2mi_image_encoder", "sam2mi_set_image_e2e", "sam2mi_memory_attention",
     "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_dense_pe", "sam2mi_video_encode", "sam2mi_video_encode_u8", "sam2mi_fill_holes", "sam2mi_set_fill_hole_area",
-    "sam2mi_video_click", "sam2mi_image_predict", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_resize_bilinear",
+    "sam2mi_video_click", "sam2mi_video_mask", "sam2mi_image_predict", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_resize_bilinear",
     "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
     "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench",
 ]
@@ -33,6 +33,11 @@ class Sam2miConfig(C.Structure):
 class MemSelect(C.Structure):
     _fields_ = [("num_mem", C.c_int), ("mem_slot", C.c_int * 16), ("mem_tpos", C.c_int * 16), ("num_ptr", C.c_int),
                 ("ptr_slot", C.c_int * 32), ("ptr_dt", C.c_float * 32), ("ptr_tmax", C.c_float)]
+
+
+class Prompt(C.Structure):
+    _fields_ = [("coords", C.c_void_p), ("labels", C.c_void_p), ("num_points", C.c_int32), ("multimask", C.c_int32),
+                ("mask_logits", C.c_void_p)]
 
 
 class FrameOut(C.Structure):
@@ -244,13 +249,25 @@ class Engine:
             setattr(fo, k, t.data_ptr() if t is not None else None)
         return fo
 
-    def video_click(self, feat_slot: int, coords: np.ndarray, labels: np.ndarray, multimask: bool, bank_slot: int, outs: dict):
+    def video_click(self, feat_slot: int, coords: np.ndarray, labels: np.ndarray, multimask: bool, bank_slot: int, outs: dict,
+                    mask_logits: Optional[torch.Tensor] = None):
         coords = np.ascontiguousarray(coords, np.float32).reshape(-1, 2)
         labels = np.ascontiguousarray(labels, np.int32).reshape(-1)
+        if mask_logits is not None:
+            _chk_f32(mask_logits)
+            assert mask_logits.numel() == 256 * 256
         fo = self._frame_out(outs)
         self._check(self.lib.sam2mi_video_click(self.h, self.stream, feat_slot, coords.ctypes.data_as(C.c_void_p),
-                                                labels.ctypes.data_as(C.c_void_p), len(labels), int(multimask), bank_slot,
+                                                labels.ctypes.data_as(C.c_void_p), len(labels), _ptr(mask_logits), int(multimask), bank_slot,
                                                 C.byref(fo)), "sam2mi_video_click")
+
+    def video_mask(self, feat_slot: int, mask1024: torch.Tensor, bank_slot: int, outs: dict):
+        """mask1024: float32 {0,1} (image_size, image_size) on the device: the mask IS the output (_use_mask_as_output)."""
+        _chk_f32(mask1024)
+        S = self.cfg["image_size"]
+        assert mask1024.numel() == S * S
+        fo = self._frame_out(outs)
+        self._check(self.lib.sam2mi_video_mask(self.h, self.stream, feat_slot, _ptr(mask1024), bank_slot, C.byref(fo)), "sam2mi_video_mask")
 
     def image_predict(self, feat_slot: int, coords: np.ndarray, labels: np.ndarray, multimask: bool):
         """coords (N, Np, 2) / labels (N, Np): N independent prompts on one image, one batched decoder pass.
@@ -272,10 +289,21 @@ class Engine:
         self._check(self.lib.sam2mi_video_encode_memory(self.h, self.stream, feat_slot, bank_slot, int(is_mask_from_pts)),
                     "sam2mi_video_encode_memory")
 
-    def video_track(self, feat_slot: int, sel: MemSelect, bank_slot: int, run_mem_encoder: bool, outs: dict):
+    def video_track(self, feat_slot: int, sel: MemSelect, bank_slot: int, run_mem_encoder: bool, outs: dict,
+                    points: Optional[np.ndarray] = None, labels: Optional[np.ndarray] = None, multimask: bool = True,
+                    mask_logits: Optional[torch.Tensor] = None):
+        """Plain propagation when `points` is None; otherwise correction clicks (+ previous mask logits) on a tracked frame."""
         fo = self._frame_out(outs)
-        self._check(self.lib.sam2mi_video_track(self.h, self.stream, feat_slot, C.byref(sel), bank_slot, int(run_mem_encoder),
-                                                C.byref(fo)), "sam2mi_video_track")
+        pr = None
+        if points is not None:
+            coords = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+            lab = np.ascontiguousarray(labels, np.int32).reshape(-1)
+            if mask_logits is not None:
+                _chk_f32(mask_logits)
+            pr = Prompt(coords.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p), len(lab), int(multimask),
+                        C.c_void_p(mask_logits.data_ptr()) if mask_logits is not None else None)
+        self._check(self.lib.sam2mi_video_track(self.h, self.stream, feat_slot, C.byref(sel), C.byref(pr) if pr is not None else None,
+                                                bank_slot, int(run_mem_encoder), C.byref(fo)), "sam2mi_video_track")
 
     # ------------------------------------------------------------------ profiling
     def profile_enable(self, on: bool):

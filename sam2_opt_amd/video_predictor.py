@@ -13,7 +13,7 @@ Differences from the reference, all deliberate:
     the tracking state; the reference encodes one frame at a time;
   * `fill_hole_area` defaults to 0 (the goldens were recorded from the reference without its CUDA extension, where the
     step is silently skipped, utils/misc.py:321-336); pass 8 (build_sam.py:129) to fill holes on the device;
-  * mask prompts (`add_new_mask`) and correction clicks on already-tracked frames are not implemented yet.
+  * `clear_non_cond_mem_around_input` and `add_all_frames_to_correct_as_cond` are fixed at their defaults (False).
 """
 from __future__ import annotations
 
@@ -86,7 +86,7 @@ class SAM2VideoPredictor:
             "images": frames, "num_frames": frames.shape[0],
             "video_height": video_height or self.image_size, "video_width": video_width or self.image_size,
             "device": self.device, "offload_video_to_cpu": offload_video_to_cpu,
-            "point_inputs_per_obj": {}, "obj_id_to_idx": OrderedDict(), "obj_idx_to_id": OrderedDict(), "obj_ids": [],
+            "point_inputs_per_obj": {}, "mask_inputs_per_obj": {}, "obj_id_to_idx": OrderedDict(), "obj_idx_to_id": OrderedDict(), "obj_ids": [],
             "output_dict_per_obj": {}, "temp_output_dict_per_obj": {}, "frames_tracked_per_obj": {},
             "feat_slot_of_frame": OrderedDict(), "free_feat_slots": list(range(self.engine.feat_slots)),
             "free_bank_slots": list(range(self.engine.bank_slots)),
@@ -101,7 +101,7 @@ class SAM2VideoPredictor:
                 for out in d[k].values():
                     self._free_bank(st, out)
                 d[k].clear()
-        for k in ("point_inputs_per_obj", "obj_id_to_idx", "obj_idx_to_id", "output_dict_per_obj",
+        for k in ("point_inputs_per_obj", "mask_inputs_per_obj", "obj_id_to_idx", "obj_idx_to_id", "output_dict_per_obj",
                   "temp_output_dict_per_obj", "frames_tracked_per_obj"):
             st[k].clear()
         st["obj_ids"] = []
@@ -115,6 +115,7 @@ class SAM2VideoPredictor:
         st["obj_idx_to_id"][idx] = obj_id
         st["obj_ids"] = list(st["obj_id_to_idx"])
         st["point_inputs_per_obj"][idx] = {}
+        st["mask_inputs_per_obj"][idx] = {}
         st["output_dict_per_obj"][idx] = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
         st["temp_output_dict_per_obj"][idx] = {"cond_frame_outputs": {}, "non_cond_frame_outputs": {}}
         st["frames_tracked_per_obj"][idx] = {}
@@ -210,25 +211,63 @@ class SAM2VideoPredictor:
             pts = np.concatenate([per_frame[frame_idx][0], pts], axis=0)
             lab = np.concatenate([per_frame[frame_idx][1], lab], axis=0)
         per_frame[frame_idx] = (pts, lab)
-        if frame_idx in st["frames_tracked_per_obj"][obj_idx]:
-            raise NotImplementedError("correction clicks on an already tracked frame are not implemented yet")
-        temp = st["temp_output_dict_per_obj"][obj_idx]["cond_frame_outputs"]
-        self._free_bank(st, temp.pop(frame_idx, None))
+        st["mask_inputs_per_obj"][obj_idx].pop(frame_idx, None)
+        # an untracked frame is an initial conditioning frame (SAM on the frame alone); a tracked one gets correction clicks on
+        # top of its memory-conditioned features (sam2_video_predictor_official.py:333-346)
+        tracked = st["frames_tracked_per_obj"][obj_idx].get(frame_idx)
+        is_init = tracked is None
+        key = "cond_frame_outputs" if is_init else "non_cond_frame_outputs"        # add_all_frames_to_correct_as_cond = False
+        od, td = st["output_dict_per_obj"][obj_idx], st["temp_output_dict_per_obj"][obj_idx]
+        # the previous prediction on this frame, if any, goes in as a mask prompt (clamped; :352-366)
+        prev = td[key].get(frame_idx) or od["cond_frame_outputs"].get(frame_idx) or od["non_cond_frame_outputs"].get(frame_idx)
+        prev_logits = torch.clamp(prev["pred_masks"], -32.0, 32.0).contiguous() if prev is not None else None
         feat = self._ensure_features(st, frame_idx)
         slot = self._alloc_bank(st)
         n = len(lab)
-        multimask = self.cfg["multimask_min_pt_num"] <= n <= self.cfg["multimask_max_pt_num"]    # _use_multimask :1181-1189
+        # _use_multimask (sam2_base_official.py:1181-1189): only on initial conditioning frames (or while tracking), 1 point
+        multimask = self.cfg["multimask_min_pt_num"] <= n <= self.cfg["multimask_max_pt_num"]
         low = self.engine.new(1, 1, 256, 256)
         score = self.engine.new(1, 1)
-        self.engine.video_click(feat, pts, lab, multimask, slot, dict(low_res_masks=low, object_score_logits=score))
-        temp[frame_idx] = dict(slot=slot, pred_masks=low, object_score_logits=score, has_mem=False, is_pts=True)
+        outs = dict(low_res_masks=low, object_score_logits=score)
+        if is_init:
+            self.engine.video_click(feat, pts, lab, multimask, slot, outs, mask_logits=prev_logits)
+        else:
+            sel = self._select_memory(od, frame_idx, st["num_frames"], tracked["reverse"])
+            self.engine.video_track(feat, sel, slot, False, outs, points=pts, labels=lab, multimask=multimask, mask_logits=prev_logits)
+        self._free_bank(st, td[key].pop(frame_idx, None))
+        td[key][frame_idx] = dict(slot=slot, pred_masks=low, object_score_logits=score, has_mem=False, is_pts=True)
         return frame_idx, st["obj_ids"], self._video_res(st, self._consolidated(st, frame_idx))
 
     def add_new_points(self, *a, **k):
         return self.add_new_points_or_box(*a, **k)
 
-    def add_new_mask(self, *a, **k):
-        raise NotImplementedError("mask prompts are not implemented on this backend yet")
+    @torch.inference_mode()
+    def add_new_mask(self, inference_state, frame_idx, obj_id, mask):
+        """Mask prompt (sam2_video_predictor_official.py:403-489): the mask becomes the frame's output as it is
+        (SAM2Base._use_mask_as_output); the SAM decoder only supplies the object pointer."""
+        st = inference_state
+        obj_idx = self._obj_id_to_idx(st, obj_id)
+        m = torch.as_tensor(np.asarray(mask) if not isinstance(mask, torch.Tensor) else mask)
+        if m.dim() != 2:
+            raise ValueError("mask must be a 2-D array")
+        m = m.to(self.device).float()[None, None]
+        S = self.image_size
+        if m.shape[-2:] != (S, S):              # host-side plumbing, like the reference: bilinear antialias, then >= 0.5
+            m = (torch.nn.functional.interpolate(m, size=(S, S), align_corners=False, mode="bilinear", antialias=True) >= 0.5).float()
+        m = m.contiguous()
+        st["mask_inputs_per_obj"][obj_idx][frame_idx] = m
+        st["point_inputs_per_obj"][obj_idx].pop(frame_idx, None)
+        is_init = frame_idx not in st["frames_tracked_per_obj"][obj_idx]
+        key = "cond_frame_outputs" if is_init else "non_cond_frame_outputs"
+        td = st["temp_output_dict_per_obj"][obj_idx]
+        feat = self._ensure_features(st, frame_idx)
+        slot = self._alloc_bank(st)
+        low = self.engine.new(1, 1, 256, 256)
+        score = self.engine.new(1, 1)
+        self.engine.video_mask(feat, m, slot, dict(low_res_masks=low, object_score_logits=score))
+        self._free_bank(st, td[key].pop(frame_idx, None))
+        td[key][frame_idx] = dict(slot=slot, pred_masks=low, object_score_logits=score, has_mem=False, is_pts=False)
+        return frame_idx, st["obj_ids"], self._video_res(st, self._consolidated(st, frame_idx))
 
     def _consolidated(self, st, frame_idx):
         """(num_obj,1,256,256) low-res logits on `frame_idx`; objects without output get NO_OBJ_SCORE (:525-570)."""

@@ -44,3 +44,43 @@ def test_video_oracle_matches_reference(sd_large, cfg_large, golden_video):
             for gk, k in (("ious", "ious"), ("obj_ptr", "obj_ptr"), ("obj_score", "object_score_logits"), ("low", "low_res_masks")):
                 ok, msg = compare(g, f"f{t}/heads/{gk}", tr[k], atol=5e-3, rtol=1e-3)
                 assert ok, msg
+
+
+def test_oracle_mask_prompt_and_correction_click_match_reference():
+    """add_new_mask (mask as output, pointer from the SAM heads), propagation from it, a negative correction click on a
+    tracked frame (memory-conditioned features + previous logits as mask prompt) and propagation from the frame after it -
+    the oracle against the REAL reference (tests/golden/large_interact6.npz, oracle/gen_golden.py interact)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import sam2_ref as R
+    from oracle.gen_golden import INTERACT_FRAMES, interact_mask
+    from oracle.golden_io import compare
+    from sam2_opt_amd.config import get_config
+    from sam2_opt_amd.synthetic import normalize_frames, synthetic_frames_u8
+    from sam2_opt_amd.weights import synthetic_state_dict
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_interact6.npz"))
+    cfg = get_config("large")
+    sd = synthetic_state_dict(cfg, seed=0)
+    frames = normalize_frames(synthetic_frames_u8(seed=4, num_frames=INTERACT_FRAMES), cfg)
+
+    def chk(name, t, atol=2e-3, frac=2e-3):
+        ok, msg = compare(gold, name, t, atol=atol, rtol=1e-3, outlier_frac=frac)
+        assert ok, msg
+    with torch.inference_mode():
+        vo = R.VideoOracle(sd, cfg, frames)
+        vm = vo.add_new_mask(0, interact_mask())
+        chk("mask0/video_res_mask", vm)
+        cur = vo.temp["cond"][0]
+        chk("mask0/pred_masks", cur["pred_masks"])
+        chk("mask0/obj_ptr", cur["obj_ptr"], atol=5e-4)
+        chk("mask0/object_score_logits", cur["object_score_logits"], atol=1e-6)
+        for t, vm in vo.propagate():
+            chk(f"p1/f{t}/video_res_mask", vm)
+        vm = vo.add_new_points(3, np.array([[600.0, 400.0]], np.float32), np.array([0], np.int32))
+        chk("fix3/video_res_mask", vm)
+        cur = vo.temp["non_cond"][3]
+        chk("fix3/obj_ptr", cur["obj_ptr"], atol=5e-4)
+        chk("fix3/object_score_logits", cur["object_score_logits"], atol=5e-4)
+        for t, vm in vo.propagate(start_frame_idx=4):
+            chk(f"p2/f{t}/video_res_mask", vm)

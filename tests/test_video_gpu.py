@@ -135,3 +135,44 @@ def test_full_clip_is_deterministic_and_prefix_consistent(predictor):
     for a, b in zip(full[:24], short):
         assert torch.equal(a, b)
     assert all(torch.isfinite(m).all() for m in full)
+
+
+def test_mask_prompt_and_correction_click_match_reference_golden(predictor):
+    """SAM2VideoPredictor.add_new_mask, propagation from a mask, a negative correction click on a tracked frame and
+    propagation from the frame after it, against golden vectors recorded from the REAL reference
+    (tests/golden/large_interact6.npz; the oracle is pinned to the same vectors in tests/test_oracle_video.py)."""
+    import os
+    from oracle.gen_golden import INTERACT_FRAMES, interact_mask
+    from sam2_opt_amd.synthetic import synthetic_frames_u8
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_interact6.npz"))
+    worst = dict(max_rel=0.0, l2=0.0, dis=0.0)
+
+    def chk(name, t):
+        got, ref = _sample(t, g, name)
+        max_rel = np.abs(got - ref).max() / np.abs(ref).max()
+        l2 = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        dis = float(((got > 0) != (ref > 0)).mean())
+        worst.update(max_rel=max(worst["max_rel"], max_rel), l2=max(worst["l2"], l2), dis=max(worst["dis"], dis))
+        assert max_rel <= 5e-3 and l2 <= 5e-3 and dis <= 2e-3, (name, max_rel, l2, dis)
+    st = predictor.init_state(frames_u8=synthetic_frames_u8(seed=4, num_frames=INTERACT_FRAMES), video_height=1024, video_width=1024)
+    _, ids, vm = predictor.add_new_mask(st, 0, 1, interact_mask())
+    chk("mask0/video_res_mask", vm)
+    out0 = st["temp_output_dict_per_obj"][0]["cond_frame_outputs"][0]
+    chk("mask0/pred_masks", out0["pred_masks"])
+    assert float(out0["object_score_logits"].item()) == 10.0
+    for t, _, vm in predictor.propagate_in_video(st):
+        chk(f"p1/f{t}/video_res_mask", vm)
+    _, _, vm = predictor.add_new_points_or_box(st, 3, 1, points=np.array([[600.0, 400.0]], np.float32), labels=np.array([0], np.int32))
+    chk("fix3/video_res_mask", vm)
+    seen = []
+    for t, _, vm in predictor.propagate_in_video(st, start_frame_idx=4):
+        chk(f"p2/f{t}/video_res_mask", vm)
+        seen.append(t)
+    assert seen == [4, 5]
+    print(f"[parity] mask prompt + correction click: max_rel={worst['max_rel']:.3e} l2={worst['l2']:.3e} pixel disagreement={worst['dis']:.3e}", flush=True)
+    predictor.reset_state(st)
+    # an empty mask: no object -> score -10, pointer = no_obj_ptr path (sam2_base_official.py:527-535)
+    _, _, vm = predictor.add_new_mask(st, 0, 1, np.zeros((1024, 1024), bool))
+    assert float(st["temp_output_dict_per_obj"][0]["cond_frame_outputs"][0]["object_score_logits"].item()) == -10.0
+    assert float(vm.max().item()) <= -9.99
+    predictor.reset_state(st)
