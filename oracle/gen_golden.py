@@ -2,7 +2,7 @@
 from /root/reference on seeded synthetic inputs and weights.  Container-only; the
 outputs (data, not code) are committed and travel to the GPU box.
 
-    python -m oracle.gen_golden [plugs] [video] [tiny] [interact]
+    python -m oracle.gen_golden [plugs] [video] [tiny] [interact] [reverse]
 
 Weights: sam2_opt_amd.weights.synthetic_state_dict(cfg, seed=0)   (regenerated anywhere)
 Inputs : sam2_opt_amd.synthetic.*  with the seeds named below.
@@ -199,6 +199,29 @@ def gen_interact():
 
 
 @torch.inference_mode()
+def gen_reverse():
+    """Reverse tracking: one click on the LAST frame of a 6-frame clip, propagate_in_video(reverse=True)."""
+    cfg = get_config("large")
+    sd = synthetic_state_dict(cfg, seed=0)
+    model = build_reference_model(cfg, "video", sd, fill_hole_area=0)
+    frames = normalize_frames(synthetic_frames_u8(seed=6, num_frames=INTERACT_FRAMES), cfg)
+    import sam2.sam2_video_predictor_official as vp
+    vp.load_video_frames = lambda **kw: (frames, 1024, 1024)
+    store = {}
+    state = model.init_state(video_path="synthetic")
+    _, _, vm = model.add_new_points_or_box(state, frame_idx=INTERACT_FRAMES - 1, obj_id=1, points=np.array([CLICK], np.float32),
+                                           labels=np.array([1], np.int32))
+    pack(store, "click/video_res_mask", vm, 16384)
+    order = []
+    for fi, ids, vm in model.propagate_in_video(state, reverse=True):
+        pack(store, f"f{fi}/video_res_mask", vm, 8192)
+        order.append(fi)
+    store["order"] = np.array(order, dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "large_reverse6.npz"), **store)
+    print("reverse done", order)
+
+
+@torch.inference_mode()
 def gen_tiny():
     """BASELINE.json configs[0]: SAM2.1-hiera-tiny image predictor, one 1024^2 frame, torch backend on the CPU - the
     reference's own CPU-runnable case.  Synthetic tiny weights, image RandomState(0), one positive click at (512, 512)."""
@@ -233,3 +256,5 @@ if __name__ == "__main__":
         gen_tiny()
     if "interact" in which:
         gen_interact()
+    if "reverse" in which:
+        gen_reverse()

@@ -486,9 +486,9 @@ def encode_new_memory(pix_feat, high_res_masks, obj_logits, is_mask_from_pts, sd
 
 
 # ----------------------------------------------------------------------------- memory bank assembly (a8)
-def assemble_memory(frame_idx, cond_outputs, non_cond_outputs, num_frames, sd, cfg):
+def assemble_memory(frame_idx, cond_outputs, non_cond_outputs, num_frames, sd, cfg, reverse=False):
     """SAM2Base._prepare_memory_conditioned_features step 1 (sam2_base_official.py:823-946),
-    forward tracking, stride 1, max_cond_frames_in_attn=-1.  Outputs dicts hold
+    forward or reverse tracking, stride 1, max_cond_frames_in_attn=-1.  Outputs dicts hold
     maskmem_features (1,64,64,64) [bf16-rounded], maskmem_pos_enc (1,64,64,64), obj_ptr (1,256).
     Returns the six plug inputs (without curr/curr_pos): memory (L,4096,1,64), memory_pos,
     memory_exclude (P,1,64), memory_pos_exclude."""
@@ -497,7 +497,7 @@ def assemble_memory(frame_idx, cond_outputs, non_cond_outputs, num_frames, sd, c
     t_pos_and_prevs = [(0, out) for out in cond_outputs.values()]
     for t_pos in range(1, nm):
         t_rel = nm - t_pos
-        t_pos_and_prevs.append((t_pos, non_cond_outputs.get(frame_idx - t_rel, None)))
+        t_pos_and_prevs.append((t_pos, non_cond_outputs.get(frame_idx + t_rel if reverse else frame_idx - t_rel, None)))
     mems, mposs = [], []
     for t_pos, prev in t_pos_and_prevs:
         if prev is None:
@@ -506,10 +506,12 @@ def assemble_memory(frame_idx, cond_outputs, non_cond_outputs, num_frames, sd, c
         enc = prev["maskmem_pos_enc"].flatten(2).permute(2, 0, 1)
         mposs.append(enc + sd["maskmem_tpos_enc"][nm - t_pos - 1])
     max_ptrs = min(num_frames, cfg["max_obj_ptrs_in_encoder"])
-    pos_and_ptrs = [(frame_idx - t, out["obj_ptr"]) for t, out in cond_outputs.items() if t <= frame_idx]
+    sign = -1 if reverse else 1                  # use_signed_tpos_enc_to_obj_ptrs, only_obj_ptrs_in_the_past_for_eval (:891-905)
+    pos_and_ptrs = [((frame_idx - t) * sign, out["obj_ptr"]) for t, out in cond_outputs.items()
+                    if (t >= frame_idx if reverse else t <= frame_idx)]
     for t_diff in range(1, max_ptrs):
-        t = frame_idx - t_diff
-        if t < 0:
+        t = frame_idx + t_diff if reverse else frame_idx - t_diff
+        if t < 0 or t >= num_frames:
             break
         out = non_cond_outputs.get(t, None)
         if out is not None:
@@ -563,13 +565,13 @@ class VideoOracle:
             return low
         return F.interpolate(low, size=(H, W), mode="bilinear", align_corners=False)
 
-    def _memory_conditioned(self, t):
+    def _memory_conditioned(self, t, reverse=False):
         cfg, sd = self.cfg, self.sd
         f = self._features(t)
         S = f[6].shape[-1]
         curr = f[6].flatten(2).permute(2, 0, 1)
         curr_pos = f[3].flatten(2).permute(2, 0, 1)
-        mem, mpos, ex, expos = assemble_memory(t, self.cond, self.non_cond, self.num_frames, sd, cfg)
+        mem, mpos, ex, expos = assemble_memory(t, self.cond, self.non_cond, self.num_frames, sd, cfg, reverse)
         pix = memory_attention(curr, mem, curr_pos, mpos, ex, expos, sd, cfg)
         return pix.permute(1, 2, 0).view(1, cfg["d_model"], S, S), (curr, mem, curr_pos, mpos, ex, expos)
 
@@ -592,7 +594,7 @@ class VideoOracle:
         if is_init:
             pix = f[6] + sd["no_mem_embed"].view(1, -1, 1, 1)      # directly_add_no_mem_embed (:953-957)
         else:
-            pix, _ = self._memory_conditioned(frame_idx)             # correction clicks on a tracked frame
+            pix, _ = self._memory_conditioned(frame_idx, self.tracked[frame_idx])      # correction clicks on a tracked frame
         n = lab.shape[1]
         multimask = cfg["multimask_min_pt_num"] <= n <= cfg["multimask_max_pt_num"]
         out = sam_heads(pix, f[4], f[5], sd, cfg, pts, lab, prev_logits, multimask)
@@ -633,10 +635,10 @@ class VideoOracle:
         for t in self.cond:
             self.non_cond.pop(t, None)
 
-    def track_frame(self, t):
+    def track_frame(self, t, reverse=False):
         cfg, sd = self.cfg, self.sd
         f = self._features(t)
-        pix, memattn_in = self._memory_conditioned(t)
+        pix, memattn_in = self._memory_conditioned(t, reverse)
         out = sam_heads(pix, f[4], f[5], sd, cfg, None, None, None, True)   # multimask for tracking
         feats, pos = encode_new_memory(f[6], out["high_res_masks"], out["object_score_logits"], False, sd, cfg)
         self.non_cond[t] = dict(pred_masks=out["low_res_masks"], obj_ptr=out["obj_ptr"],
@@ -645,16 +647,21 @@ class VideoOracle:
         self.trace[("track", t)] = dict(out, memattn_in=memattn_in, pix_feat=pix, maskmem_features=feats)
         return out["low_res_masks"]
 
-    def propagate(self, max_frames=None, start_frame_idx=None):
+    def propagate(self, max_frames=None, start_frame_idx=None, reverse=False):
         self._preflight()
         start = min(self.cond) if start_frame_idx is None else start_frame_idx
-        end = self.num_frames - 1 if max_frames is None else min(start + max_frames, self.num_frames - 1)
-        for t in range(start, end + 1):
+        if max_frames is None:
+            max_frames = self.num_frames
+        if reverse:                                  # processing order of propagate_in_video (:675-686)
+            order = range(start, max(start - max_frames, 0) - 1, -1) if start > 0 else []
+        else:
+            order = range(start, min(start + max_frames, self.num_frames - 1) + 1)
+        for t in order:
             if t in self.cond:
                 low = self.cond[t]["pred_masks"]
             else:
-                low = self.track_frame(t)
-            self.tracked[t] = False
+                low = self.track_frame(t, reverse)
+            self.tracked[t] = reverse
             yield t, self._video_res(low)
 
 

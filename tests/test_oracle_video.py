@@ -84,3 +84,32 @@ def test_oracle_mask_prompt_and_correction_click_match_reference():
         chk("fix3/object_score_logits", cur["object_score_logits"], atol=5e-4)
         for t, vm in vo.propagate(start_frame_idx=4):
             chk(f"p2/f{t}/video_res_mask", vm)
+
+
+def test_oracle_reverse_tracking_matches_reference():
+    """propagate_in_video(reverse=True) from a click on the last frame (signed pointer offsets, memories taken from later
+    frames) - the oracle against the REAL reference (tests/golden/large_reverse6.npz)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import sam2_ref as R
+    from oracle.gen_golden import CLICK, INTERACT_FRAMES
+    from oracle.golden_io import compare
+    from sam2_opt_amd.config import get_config
+    from sam2_opt_amd.synthetic import normalize_frames, synthetic_frames_u8
+    from sam2_opt_amd.weights import synthetic_state_dict
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_reverse6.npz"))
+    cfg = get_config("large")
+    sd = synthetic_state_dict(cfg, seed=0)
+    frames = normalize_frames(synthetic_frames_u8(seed=6, num_frames=INTERACT_FRAMES), cfg)
+    with torch.inference_mode():
+        vo = R.VideoOracle(sd, cfg, frames)
+        vm = vo.add_new_points(INTERACT_FRAMES - 1, np.array([CLICK], np.float32), np.array([1], np.int32))
+        ok, msg = compare(gold, "click/video_res_mask", vm, atol=2e-3, rtol=1e-3, outlier_frac=2e-3)
+        assert ok, msg
+        order = []
+        for t, vm in vo.propagate(reverse=True):
+            ok, msg = compare(gold, f"f{t}/video_res_mask", vm, atol=2e-3, rtol=1e-3, outlier_frac=2e-3)
+            assert ok, msg
+            order.append(t)
+    assert order == list(gold["order"])

@@ -176,3 +176,25 @@ def test_mask_prompt_and_correction_click_match_reference_golden(predictor):
     assert float(st["temp_output_dict_per_obj"][0]["cond_frame_outputs"][0]["object_score_logits"].item()) == -10.0
     assert float(vm.max().item()) <= -9.99
     predictor.reset_state(st)
+
+
+def test_reverse_tracking_matches_reference_golden(predictor):
+    """propagate_in_video(reverse=True) from a click on the last frame vs the REAL reference (tests/golden/large_reverse6.npz)."""
+    import os
+    from oracle.gen_golden import INTERACT_FRAMES
+    from sam2_opt_amd.synthetic import synthetic_frames_u8
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_reverse6.npz"))
+    st = predictor.init_state(frames_u8=synthetic_frames_u8(seed=6, num_frames=INTERACT_FRAMES), video_height=1024, video_width=1024)
+    predictor.add_new_points_or_box(st, INTERACT_FRAMES - 1, 1, points=np.array([CLICK], np.float32), labels=np.array([1], np.int32))
+    order, worst = [], 0.0
+    for t, _, vm in predictor.propagate_in_video(st, reverse=True):
+        got, ref = _sample(vm, g, f"f{t}/video_res_mask")
+        max_rel = np.abs(got - ref).max() / np.abs(ref).max()
+        l2 = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        dis = float(((got > 0) != (ref > 0)).mean())
+        assert max_rel <= 5e-3 and l2 <= 5e-3 and dis <= 2e-3, (t, max_rel, l2, dis)
+        worst = max(worst, l2)
+        order.append(t)
+    assert order == list(g["order"])
+    print(f"[parity] reverse tracking: worst rel-L2 {worst:.3e}", flush=True)
+    predictor.reset_state(st)
