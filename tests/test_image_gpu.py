@@ -40,3 +40,27 @@ def test_image_predictor_matches_oracle(sd_large, cfg_large):
         assert mb.shape == (3, 1024, 1024) and set(np.unique(mb)) <= {0.0, 1.0} and sb.shape == (3,) and lb.shape == (3, 256, 256)
     finally:
         pred.release()
+
+
+def test_batched_prompts_equal_single_prompt_calls(sd_large):
+    """The decoder batches prompts (chunks of 16, SURVEY 8 f-4: the automatic mask generator's prompt batches): 20 prompts on
+    one image in one call give exactly what 20 single-prompt calls give."""
+    from sam2_opt_amd.image_predictor import SAM2ImagePredictor
+    img = np.random.RandomState(3).randint(0, 256, (1024, 1024, 3)).astype(np.uint8)
+    pred = SAM2ImagePredictor("large", state_dict=sd_large, max_batch=1)
+    try:
+        pred.set_image(img)
+        pts = (np.random.RandomState(5).rand(20, 1, 2) * 1024).astype(np.float32)
+        lab = np.ones((20, 1), np.int32)
+        m, s, l = pred._predict(pts, lab, None, None, True, True, True, 0)
+        assert m.shape == (20, 3, 1024, 1024) and s.shape == (20, 3)
+        for i in (0, 7, 15, 16, 19):
+            mi, si, li = pred._predict(pts[i:i + 1], lab[i:i + 1], None, None, True, True, True, 0)
+            assert torch.equal(mi[0], m[i]) and torch.equal(si[0], s[i]) and torch.equal(li[0], l[i])
+        # single-mask output (stability fallback) for a batch as well
+        m1, s1, _ = pred._predict(pts[:18], lab[:18], None, None, False, True, True, 0)
+        assert m1.shape == (18, 1, 1024, 1024) and s1.shape == (18, 1)
+        m2, s2, _ = pred._predict(pts[17:18], lab[17:18], None, None, False, True, True, 0)
+        assert torch.equal(m2[0], m1[17]) and torch.equal(s2[0], s1[17])
+    finally:
+        pred.release()
