@@ -303,7 +303,9 @@ static inline long tiles_of(const GemmParams& p, int bm, int bn) { return (long)
 // 8-wave workgroups beat 4-wave ones on every large shape; 128x128 (2 per CU) wins when N pads to 128 with <= 8 % waste,
 // 128x64 (3 per CU) otherwise; 256x128 and 3/4-stage rings (1 workgroup per CU) lose 30-50 %, 16-wave 256x128 3-stage
 // workgroups lose 10 %, a 256x256 8-wave tile on this loop structure loses 50 % (it needs the fine-grained multi-phase
-// schedule, not more bytes per barrier).  The loop is bound by the per-CU L2->LDS rate (~25-29 B/clk) at these tiles.
+// schedule, not more bytes per barrier; re-measured after making sure its accumulators stay in registers - with the tile
+// loops of the epilogue merely "#pragma unroll"ed the 8-tile body is not unrolled, acc[][] is indexed dynamically and lands
+// in scratch).  The loop is bound by the per-CU L2->LDS rate (~25-29 B/clk) at these tiles.
 hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   const int force = p.tile_hint;
   if (force == 6) return gemm_v3_launch(p, s);
@@ -318,11 +320,10 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   if (force == 13) return v2_launch<128, 64, 4, 2, 2>(p, s);
   if (force == 4) return v2_launch<128, 64, 2, 2, 2>(p, s);
   if (force == 5) return v2_launch<64, 64, 2, 2, 2>(p, s);
-  if (tiles_of(p, 128, 64) >= 2048) {
-    const int n128 = ((p.N + 127) / 128) * 128;
-    const long t128 = tiles_of(p, 128, 128);
-    if ((t128 >= 1536 || (t128 >= 512 && p.K >= 2048)) && (n128 - p.N) * 100 <= 8 * p.N) return v2_launch<128, 128, 4, 2, 2>(p, s);
-    return v2_launch<128, 64, 4, 2, 2>(p, s);
-  }
+  const int n128 = ((p.N + 127) / 128) * 128;
+  const long t128 = tiles_of(p, 128, 128);
+  const bool fits128 = (n128 - p.N) * 100 <= 8 * p.N;              // N pads to 128 with at most 8 % waste
+  if (fits128 && (t128 >= 1536 || (t128 >= 512 && p.K >= 2048))) return v2_launch<128, 128, 4, 2, 2>(p, s);
+  if (tiles_of(p, 128, 64) >= 1024) return v2_launch<128, 64, 4, 2, 2>(p, s);
   return v2_launch<64, 64, 2, 2, 2>(p, s);
 }
