@@ -165,6 +165,14 @@ typedef struct sam2mi_prompt {
 int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, const sam2mi_mem_select* sel, const sam2mi_prompt* prompt,
                        int bank_slot, int run_mem_encoder, const sam2mi_frame_out* out);
 
+/* N objects of one frame in one pass (plain propagation, no prompts; 1 <= N <= 8).  The reference loops objects with B = 1
+ * over shared frame features (sam2_video_predictor_official.py:691-725); here the memory-attention projections / FFN /
+ * LayerNorms run on N*4096 rows and the mask decoder on N prompts - only the two attentions over each object's own memory
+ * bank and the memory encoder stay per object.  sels[N], bank_slots[N], outs[N] (or NULL).  Results are identical to N
+ * sam2mi_video_track calls. */
+int sam2mi_video_track_batch(sam2mi_ctx* ctx, void* stream, int feat_slot, int N, const sam2mi_mem_select* sels,
+                             const int32_t* bank_slots, int run_mem_encoder, const sam2mi_frame_out* outs);
+
 /* Image predictor: prompt encoder + mask decoder on a cached frame (SAM2ImagePredictor._predict,
  * sam2_image_predictor.py:487-589: features + no_mem_embed, no object-score gating).  N independent prompts of Np points each
  * on the SAME image (coords [N,Np,2] pixels at image_size, labels [N,Np]: 0/1 points, 2/3 box corners) - the repeat_image case

@@ -203,7 +203,9 @@ int encoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, con
 int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& blk, int B, int& H, int& W, int& wcur);
 
 // engine_track.hip
-int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const float* curr_pos, int Nk, int n_rope, float* out32);
+constexpr int TRACK_MAX_N = 8;    // objects per batched tracking call (workspace size)
+int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const float* curr_pos, int N, const int* Nk, const int* n_rope,
+                    float* out32);
 constexpr int DEC_MAX_N = 16;     // prompts / objects per batched mask-decoder call (workspace size)
 struct DecoderIn {
   const float* keys_tok; size_t keys_stride;                    // floats between prompts; 0: one image for all (repeat_image)

@@ -95,7 +95,7 @@ extern "C" int sam2mi_memory_attention(sam2mi_ctx* ctx, void* stream, const floa
     CHK(cast_add_launch(memory_exclude, 64, memory_pos_exclude, 64, 0, 1.f, P, 64, ctx->t_kin16 + (size_t)n_rope * 64, 64, nullptr, 0, s));
     CHK(cast_add_launch(memory_exclude, 64, nullptr, 0, 0, 0.f, P, 64, ctx->t_vin16 + (size_t)n_rope * 64, 64, nullptr, 0, s));
   }
-  return memattn_forward(ctx, s, curr, curr_pos, Nk, n_rope, out);
+  return memattn_forward(ctx, s, curr, curr_pos, 1, &Nk, &n_rope, out);
 }
 
 // ------------------------------------------------------------------ mask decoder plug
@@ -212,11 +212,13 @@ extern "C" int sam2mi_video_encode_u8(sam2mi_ctx* ctx, void* stream, const uint8
 // `fill_before_outputs`: hole filling of the stored low-res mask (fill_holes_in_mask_scores on pred_masks,
 // sam2_video_predictor_official.py:889-894) happens here; a tracked frame passes `mem_feat_slot >= 0` to run its
 // memory encoder on the UNFILLED mask first, as track_step does (sam2_base_official.py:1151-1166 precedes :889).
+// `n`: which prompt / object of the batched decoder pass (results in ctx->d_masks [n], d_iou [n], d_obj [n], d_mtok [n]).
 static int sam_heads_finish(sam2mi_ctx* ctx, hipStream_t s, int multimask, int bank_slot, const sam2mi_frame_out* out,
-                            int mem_feat_slot = -1) {
+                            int mem_feat_slot = -1, int n = 0) {
   sam2mi_ctx::BankSlot& bk = ctx->bank[bank_slot];
-  CHK(select_mask_launch(ctx->d_masks, ctx->d_iou, ctx->d_obj, ctx->d_mtok, multimask, ctx->d_best + 2, 0.05f, 0.98f,
-                         ctx->d_low_multi, bk.low_mask, ctx->d_tok_sel, ctx->d_best, ctx->d_iou_sel, s));
+  const float* d_obj = ctx->d_obj + n;
+  CHK(select_mask_launch(ctx->d_masks + (size_t)n * 4 * 65536, ctx->d_iou + n * 4, d_obj, ctx->d_mtok + (size_t)n * 1024, multimask, ctx->d_best + 2,
+                         0.05f, 0.98f, ctx->d_low_multi, bk.low_mask, ctx->d_tok_sel, ctx->d_best, ctx->d_iou_sel, s));
   // obj_ptr = MLP3(token) gated by the object score (sam2_base_official.py:474-484)
   {
     Mlp3Batch B;
@@ -227,8 +229,8 @@ static int sam_heads_finish(sam2mi_ctx* ctx, hipStream_t s, int multimask, int b
     for (int i = 0; i < 3; ++i) { g.W[i] = ctx->ptr_proj[i].w; g.b[i] = ctx->ptr_proj[i].b; }
     CHK(mlp3_launch(B, s));
   }
-  CHK(gate_obj_ptr_launch(bk.obj_ptr, ctx->no_obj_ptr, ctx->d_obj, 256, s));
-  CHK(hipMemcpyAsync(bk.obj_score, ctx->d_obj, sizeof(float), hipMemcpyDeviceToDevice, s));
+  CHK(gate_obj_ptr_launch(bk.obj_ptr, ctx->no_obj_ptr, d_obj, 256, s));
+  CHK(hipMemcpyAsync(bk.obj_score, d_obj, sizeof(float), hipMemcpyDeviceToDevice, s));
   if (mem_feat_slot >= 0) CHKI(sam2mi_video_encode_memory(ctx, (void*)s, mem_feat_slot, bank_slot, 0));
   if (ctx->fill_hole_area > 0) {
     CHK(fill_holes_launch(bk.low_mask, ctx->d_fill_tmp, 1, 256, 256, ctx->fill_hole_area, s));
@@ -240,7 +242,7 @@ static int sam_heads_finish(sam2mi_ctx* ctx, hipStream_t s, int multimask, int b
     if (out->low_res_multimasks) CHK(hipMemcpyAsync(out->low_res_multimasks, ctx->d_low_multi, (size_t)nm * 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out->ious) CHK(hipMemcpyAsync(out->ious, ctx->d_iou_sel, nm * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out->obj_ptr) CHK(hipMemcpyAsync(out->obj_ptr, bk.obj_ptr, 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (out->object_score_logits) CHK(hipMemcpyAsync(out->object_score_logits, ctx->d_obj, sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out->object_score_logits) CHK(hipMemcpyAsync(out->object_score_logits, d_obj, sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out->best_idx) CHK(hipMemcpyAsync(out->best_idx, ctx->d_best, sizeof(int), hipMemcpyDeviceToDevice, s));
   }
   return 0;
@@ -382,16 +384,13 @@ extern "C" int sam2mi_video_encode_memory(sam2mi_ctx* ctx, void* stream, int fea
   return 0;
 }
 
-extern "C" int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, const sam2mi_mem_select* sel, const sam2mi_prompt* prompt,
-                                  int bank_slot, int run_mem_encoder, const sam2mi_frame_out* out) {
-  REQUIRE_READY();
-  hipStream_t s = S(stream);
-  if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size() || bank_slot < 0 || bank_slot >= (int)ctx->bank.size())
-    return sam2mi_set_error(ctx, __func__, "slot out of range");
+// memory bank of one object -> ctx->t_kin16 / t_vin16 (+ object-pointer tokens) at workspace lane `n`
+static int assemble_object_memory(sam2mi_ctx* ctx, hipStream_t s, const sam2mi_mem_select* sel, int n, int& Nk, int& n_rope) {
   if (!sel || sel->num_mem <= 0 || sel->num_mem > 8 || sel->num_ptr < 0 || sel->num_ptr > 32)
-    return sam2mi_set_error(ctx, __func__, "memory selection out of range (1..8 memories, 0..32 pointers)");
-  const sam2mi_ctx::FeatSlot& f = ctx->feats[feat_slot];
+    return sam2mi_set_error(ctx, "video_track", "memory selection out of range (1..8 memories, 0..32 pointers)");
   const int L = sel->num_mem, P = 4 * sel->num_ptr;
+  float* ptr_tok = ctx->t_ptr_tok + (size_t)n * 128 * 64;
+  float* ptr_pos = ctx->t_ptr_pos + (size_t)n * 128 * 64;
   // object-pointer tokens + their temporal position encoding
   if (sel->num_ptr > 0) {
     PtrTokParams pp;
@@ -399,11 +398,11 @@ extern "C" int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, 
     pp.n = sel->num_ptr;
     for (int i = 0; i < pp.n; ++i) {
       const int sl = sel->ptr_slot[i];
-      if (sl < 0 || sl >= (int)ctx->bank.size()) return sam2mi_set_error(ctx, __func__, "pointer slot out of range");
+      if (sl < 0 || sl >= (int)ctx->bank.size()) return sam2mi_set_error(ctx, "video_track", "pointer slot out of range");
       pp.ptr[i] = ctx->bank[sl].obj_ptr;
       pp.dt[i] = sel->ptr_dt[i];
     }
-    pp.tmax = sel->ptr_tmax; pp.Wt = ctx->tpos_proj.w; pp.bt = ctx->tpos_proj.b; pp.tok = ctx->t_ptr_tok; pp.pos = ctx->t_ptr_pos;
+    pp.tmax = sel->ptr_tmax; pp.Wt = ctx->tpos_proj.w; pp.bt = ctx->tpos_proj.b; pp.tok = ptr_tok; pp.pos = ptr_pos;
     CHK(ptr_tokens_launch(pp, s));
   }
   MemAssembleParams ma;
@@ -412,14 +411,28 @@ extern "C" int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, 
   for (int i = 0; i < L; ++i) {
     const int sl = sel->mem_slot[i];
     if (sl < 0 || sl >= (int)ctx->bank.size() || sel->mem_tpos[i] < 0 || sel->mem_tpos[i] >= 7)
-      return sam2mi_set_error(ctx, __func__, "memory slot / tpos out of range");
+      return sam2mi_set_error(ctx, "video_track", "memory slot / tpos out of range");
     ma.feat[i] = ctx->bank[sl].mem;
     ma.tpos[i] = ctx->tpos_enc + sel->mem_tpos[i] * 64;
   }
-  ma.pos = ctx->mem_pos; ma.ptr_tok = ctx->t_ptr_tok; ma.ptr_pos = ctx->t_ptr_pos; ma.P = P;
-  ma.kin = ctx->t_kin16; ma.vin = ctx->t_vin16;
+  ma.pos = ctx->mem_pos; ma.ptr_tok = ptr_tok; ma.ptr_pos = ptr_pos; ma.P = P;
+  ma.kin = ctx->t_kin16 + (size_t)n * ctx->t_nk_cap * 64; ma.vin = ctx->t_vin16 + (size_t)n * ctx->t_nk_cap * 64;
   CHK(mem_assemble_launch(ma, s));
-  CHKI(memattn_forward(ctx, s, f.feat2, ctx->sine_pe_tok64, L * 4096 + P, L * 4096, ctx->t_pix));
+  Nk = L * 4096 + P;
+  n_rope = L * 4096;
+  return 0;
+}
+
+extern "C" int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, const sam2mi_mem_select* sel, const sam2mi_prompt* prompt,
+                                  int bank_slot, int run_mem_encoder, const sam2mi_frame_out* out) {
+  REQUIRE_READY();
+  hipStream_t s = S(stream);
+  if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size() || bank_slot < 0 || bank_slot >= (int)ctx->bank.size())
+    return sam2mi_set_error(ctx, __func__, "slot out of range");
+  const sam2mi_ctx::FeatSlot& f = ctx->feats[feat_slot];
+  int Nk = 0, n_rope = 0;
+  CHKI(assemble_object_memory(ctx, s, sel, 0, Nk, n_rope));
+  CHKI(memattn_forward(ctx, s, f.feat2, ctx->sine_pe_tok64, 1, &Nk, &n_rope, ctx->t_pix));
   if (out && out->pix_feat) CHK(hipMemcpyAsync(out->pix_feat, ctx->t_pix, (size_t)4096 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
   int T = 0;
   const bool has_pts = prompt && prompt->num_points > 0;
@@ -436,5 +449,37 @@ extern "C" int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, 
   if (prompt && prompt->mask_logits) CHKI(one_image_in_mask(ctx, s, f, ctx->t_pix, prompt->mask_logits, in));
   CHKI(decoder_forward(ctx, s, in, 1, T));
   CHKI(sam_heads_finish(ctx, s, prompt ? prompt->multimask : 1, bank_slot, out, run_mem_encoder ? feat_slot : -1));
+  return 0;
+}
+
+// N objects of one frame in one pass (plain propagation, no prompts): the reference loops objects with B = 1
+// (sam2_video_predictor_official.py:691-725); here the memory-attention GEMMs / LayerNorms run on N * 4096 rows and the mask
+// decoder on N "prompts", only the attentions over each object's own memory bank and the memory encoder stay per object.
+extern "C" int sam2mi_video_track_batch(sam2mi_ctx* ctx, void* stream, int feat_slot, int N, const sam2mi_mem_select* sels,
+                                        const int32_t* bank_slots, int run_mem_encoder, const sam2mi_frame_out* outs) {
+  REQUIRE_READY();
+  hipStream_t s = S(stream);
+  if (N < 1 || N > TRACK_MAX_N) return sam2mi_set_error(ctx, __func__, "object batch out of range (1..8)");
+  if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size()) return sam2mi_set_error(ctx, __func__, "slot out of range");
+  for (int n = 0; n < N; ++n)
+    if (bank_slots[n] < 0 || bank_slots[n] >= (int)ctx->bank.size()) return sam2mi_set_error(ctx, __func__, "bank slot out of range");
+  const sam2mi_ctx::FeatSlot& f = ctx->feats[feat_slot];
+  int Nk[TRACK_MAX_N], n_rope[TRACK_MAX_N];
+  for (int n = 0; n < N; ++n) CHKI(assemble_object_memory(ctx, s, sels + n, n, Nk[n], n_rope[n]));
+  CHKI(memattn_forward(ctx, s, f.feat2, ctx->sine_pe_tok64, N, Nk, n_rope, ctx->t_pix));
+  int T = 0;
+  CHKI(build_tokens(ctx, s, nullptr, nullptr, 1, 0, T));        // no prompt: one padding point + pad (as above), same for every object
+  CHK(hipMemcpyAsync(ctx->d_sparse + (size_t)T * 256, ctx->d_sparse + (size_t)(T - 1) * 256, 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  T += 1;
+  for (int n = 1; n < N; ++n)
+    CHK(hipMemcpyAsync(ctx->d_sparse + (size_t)n * T * 256, ctx->d_sparse, (size_t)T * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  DecoderIn in{ctx->t_pix, (size_t)4096 * 256, ctx->no_mask_embed, 1, 0, ctx->dense_pe, true, ctx->d_sparse, f.fpn0, 0, f.fpn1, 0};
+  CHKI(decoder_forward(ctx, s, in, N, T));
+  for (int n = 0; n < N; ++n) {
+    const sam2mi_frame_out* out = outs ? outs + n : nullptr;
+    if (out && out->pix_feat)
+      CHK(hipMemcpyAsync(out->pix_feat, ctx->t_pix + (size_t)n * 4096 * 256, (size_t)4096 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CHKI(sam_heads_finish(ctx, s, 1, bank_slots[n], out, run_mem_encoder ? feat_slot : -1, n));
+  }
   return 0;
 }

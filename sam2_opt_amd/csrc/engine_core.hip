@@ -621,17 +621,17 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   // tracking (B = 1)
   const int NKCAP = 7 * 4096 + 64 * 4 + 4096;         // generous: many conditioning frames are rejected above this
   ctx->t_nk_cap = NKCAP;
-  ALLOC(ctx->t_x, float, 4096 * 256);
-  ALLOC(ctx->t_h16, half_t, 4096 * 256);
-  ALLOC(ctx->t_qk16, half_t, 4096 * 512);
-  ALLOC(ctx->t_vT16, half_t, 256 * 4096);
-  ALLOC(ctx->t_o16, half_t, 4096 * 256);
-  ALLOC(ctx->t_q16, half_t, 4096 * 256);
-  ALLOC(ctx->t_ff16, half_t, 4096 * 2048);
-  ALLOC(ctx->t_kin16, half_t, (size_t)NKCAP * 64);
-  ALLOC(ctx->t_vin16, half_t, (size_t)NKCAP * 64);
-  ALLOC(ctx->t_kall16, half_t, (size_t)NKCAP * 1024);
-  ALLOC(ctx->t_vTall16, half_t, (size_t)1024 * NKCAP);
+  ALLOC(ctx->t_x, float, (size_t)TRACK_MAX_N * 4096 * 256);
+  ALLOC(ctx->t_h16, half_t, (size_t)TRACK_MAX_N * 4096 * 256);
+  ALLOC(ctx->t_qk16, half_t, (size_t)TRACK_MAX_N * 4096 * 512);
+  ALLOC(ctx->t_vT16, half_t, (size_t)TRACK_MAX_N * 256 * 4096);
+  ALLOC(ctx->t_o16, half_t, (size_t)TRACK_MAX_N * 4096 * 256);
+  ALLOC(ctx->t_q16, half_t, (size_t)TRACK_MAX_N * 4096 * 256);
+  ALLOC(ctx->t_ff16, half_t, (size_t)TRACK_MAX_N * 4096 * 2048);
+  ALLOC(ctx->t_kin16, half_t, (size_t)TRACK_MAX_N * NKCAP * 64);
+  ALLOC(ctx->t_vin16, half_t, (size_t)TRACK_MAX_N * NKCAP * 64);
+  ALLOC(ctx->t_kall16, half_t, (size_t)TRACK_MAX_N * NKCAP * 1024);
+  ALLOC(ctx->t_vTall16, half_t, (size_t)TRACK_MAX_N * 1024 * NKCAP);
   ALLOC(ctx->t_opart, float, (size_t)16 * 4096 * 256);
   ALLOC(ctx->d_fill_tmp, float, (size_t)65536);
   ALLOC(ctx->d_mask256, float, (size_t)65536);
@@ -639,9 +639,9 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ALLOC(ctx->d_pm10, float, 2);
   ALLOC(ctx->d_flag, int, 2);
   ALLOC(ctx->t_ml, float, (size_t)16 * 4096 * 2);
-  ALLOC(ctx->t_ptr_tok, float, 128 * 64);
-  ALLOC(ctx->t_ptr_pos, float, 128 * 64);
-  ALLOC(ctx->t_pix, float, 4096 * 256);
+  ALLOC(ctx->t_ptr_tok, float, (size_t)TRACK_MAX_N * 128 * 64);
+  ALLOC(ctx->t_ptr_pos, float, (size_t)TRACK_MAX_N * 128 * 64);
+  ALLOC(ctx->t_pix, float, (size_t)TRACK_MAX_N * 4096 * 256);
   // decoder
   ALLOC(ctx->d_keys, float, (size_t)DEC_MAX_N * 4096 * 256);
   ALLOC(ctx->d_keys16, half_t, (size_t)DEC_MAX_N * 4096 * 256);

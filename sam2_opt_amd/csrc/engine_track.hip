@@ -7,84 +7,90 @@ static inline int ceil32(int v) { return (v + 31) / 32 * 32; }
 
 
 // MemoryAttention.inference_memory_attention_torch (modeling/memory_attention.py:299-349) with
-// MemoryAttentionLayer.forward (:93-109) and RoPEAttention.forward (sam/transformer.py:345-424).
-// Inputs: curr / curr_pos [4096,256] f32; ctx->t_kin16 / t_vin16 hold f16(memory+pos) / f16(memory)
-// for Nk keys of which the first n_rope get RoPE.  Output [4096,256] f32.
-int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const float* curr_pos, int Nk, int n_rope, float* out32) {
+// MemoryAttentionLayer.forward (:93-109) and RoPEAttention.forward (sam/transformer.py:345-424), for N objects of one
+// frame at once (N <= TRACK_MAX_N): every projection / FFN GEMM and LayerNorm runs on N * 4096 rows, the two attentions per
+// object (each object has its own memory bank).  Inputs: curr / curr_pos [4096,256] f32 (shared by the objects);
+// ctx->t_kin16 / t_vin16 + n * t_nk_cap * 64 hold f16(memory+pos) / f16(memory) of object n: Nk[n] keys of which the first
+// n_rope[n] get RoPE.  Output [N,4096,256] f32.
+int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const float* curr_pos, int N, const int* Nk, const int* n_rope,
+                    float* out32) {
   const int S = 4096, C = 256;
-  if (Nk <= 0 || ceil32(Nk) > ctx->t_nk_cap) return sam2mi_set_error(ctx, "memattn_forward", "memory length out of range");
-  const int NkP = ceil32(Nk);
+  if (N < 1 || N > TRACK_MAX_N) return sam2mi_set_error(ctx, "memattn_forward", "object batch out of range (1..TRACK_MAX_N)");
+  const int M = N * S;
+  const size_t cap = (size_t)ctx->t_nk_cap;
   float* x = ctx->t_x;
-  // x = curr + 0.1 * curr_pos   (pos_enc_at_input, :319-321)
-  CHK(cast_add_launch(curr, C, curr_pos, C, 0, 0.1f, S, C, nullptr, 0, x, C, s));
-  // K / V of the memory for all 4 layers at once: K_all [Nk, 4*256] (RoPE on rows < n_rope), V^T_all [4*256, NkP]
-  {
-    GemmParams p = lin_params(ctx->t_kin16, 64, Nk, ctx->cross_k_all);
-    p.out16 = ctx->t_kall16; p.ld16 = 1024;
-    p.rope_cos = ctx->rope_cos; p.rope_sin = ctx->rope_sin; p.rope_len = S; p.rope_rows = n_rope; p.rope_cols = 1024; p.rope_dim = C;
+  for (int n = 0; n < N; ++n) {
+    if (Nk[n] <= 0 || ceil32(Nk[n]) > ctx->t_nk_cap) return sam2mi_set_error(ctx, "memattn_forward", "memory length out of range");
+    // x = curr + 0.1 * curr_pos   (pos_enc_at_input, :319-321)
+    CHK(cast_add_launch(curr, C, curr_pos, C, 0, 0.1f, S, C, nullptr, 0, x + (size_t)n * S * C, C, s));
+    // K / V of the memory for all 4 layers at once: K_all [Nk, 4*256] (RoPE on rows < n_rope), V^T_all [4*256, NkP]
+    GemmParams p = lin_params(ctx->t_kin16 + n * cap * 64, 64, Nk[n], ctx->cross_k_all);
+    p.out16 = ctx->t_kall16 + n * cap * 1024; p.ld16 = 1024;
+    p.rope_cos = ctx->rope_cos; p.rope_sin = ctx->rope_sin; p.rope_len = S; p.rope_rows = n_rope[n]; p.rope_cols = 1024; p.rope_dim = C;
     CHKI(run_gemm(ctx, s, p));
-    GemmParams q = lin_params(ctx->t_vin16, 64, Nk, ctx->cross_v_all);
-    q.n_split = 0; q.outT16 = ctx->t_vTall16; q.ldT16 = NkP;
+    GemmParams q = lin_params(ctx->t_vin16 + n * cap * 64, 64, Nk[n], ctx->cross_v_all);
+    q.n_split = 0; q.outT16 = ctx->t_vTall16 + n * cap * 1024; q.ldT16 = ceil32(Nk[n]);
     CHKI(run_gemm(ctx, s, q));
   }
   for (int l = 0; l < 4; ++l) {
     const MemAttnLayerW& L = ctx->mal[l];
     // ---- self attention
-    CHK(layernorm_launch(x, C, L.n1.w, L.n1.b, 1e-5f, S, C, ctx->t_h16, C, nullptr, 0, 0, s));
+    CHK(layernorm_launch(x, C, L.n1.w, L.n1.b, 1e-5f, M, C, ctx->t_h16, C, nullptr, 0, 0, s));
     {
-      GemmParams p = lin_params(ctx->t_h16, C, S, L.self_qkv);
-      p.n_split = 512; p.out16 = ctx->t_qk16; p.ld16 = 512; p.outT16 = ctx->t_vT16; p.ldT16 = S;
+      GemmParams p = lin_params(ctx->t_h16, C, M, L.self_qkv);
+      p.n_split = 512; p.out16 = ctx->t_qk16; p.ld16 = 512; p.outT16 = ctx->t_vT16; p.ldT16 = M;
       p.col_scale = ctx->qs_self;
-      p.rope_cos = ctx->rope_cos; p.rope_sin = ctx->rope_sin; p.rope_len = S; p.rope_rows = S; p.rope_cols = 512; p.rope_dim = C;
+      p.rope_cos = ctx->rope_cos; p.rope_sin = ctx->rope_sin; p.rope_len = S; p.rope_rows = M; p.rope_cols = 512; p.rope_dim = C;
       CHKI(run_gemm(ctx, s, p));
     }
-    {
+    for (int n = 0; n < N; ++n) {
       Flash256Params f;
       memset(&f, 0, sizeof(f));
-      f.q = ctx->t_qk16; f.ldq = 512; f.k = ctx->t_qk16 + 256; f.ldk = 512; f.vT = ctx->t_vT16; f.ldvT = S;
+      f.q = ctx->t_qk16 + (size_t)n * S * 512; f.ldq = 512; f.k = f.q + 256; f.ldk = 512; f.vT = ctx->t_vT16 + (size_t)n * S; f.ldvT = M;
       f.Nq = S; f.Nk = S; f.splits = flash256_pick_splits(S, S); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
-      f.out = ctx->t_o16; f.ldout = C; f.scale_log2e = LOG2E / 16.f;
+      f.out = ctx->t_o16 + (size_t)n * S * C; f.ldout = C; f.scale_log2e = LOG2E / 16.f;
       CHKI(run_flash256(ctx, s, f));
     }
     {
-      GemmParams p = lin_params(ctx->t_o16, C, S, L.self_out);
+      GemmParams p = lin_params(ctx->t_o16, C, M, L.self_out);
       p.res = x; p.ldres = C; p.out32 = x; p.ld32 = C;
       CHKI(run_gemm(ctx, s, p));
     }
     // ---- cross attention to the memory bank
-    CHK(layernorm_launch(x, C, L.n2.w, L.n2.b, 1e-5f, S, C, ctx->t_h16, C, nullptr, 0, 0, s));
+    CHK(layernorm_launch(x, C, L.n2.w, L.n2.b, 1e-5f, M, C, ctx->t_h16, C, nullptr, 0, 0, s));
     {
-      GemmParams p = lin_params(ctx->t_h16, C, S, L.cross_q);
+      GemmParams p = lin_params(ctx->t_h16, C, M, L.cross_q);
       p.out16 = ctx->t_q16; p.ld16 = C; p.col_scale = ctx->qs_cross;
-      p.rope_cos = ctx->rope_cos; p.rope_sin = ctx->rope_sin; p.rope_len = S; p.rope_rows = S; p.rope_cols = C; p.rope_dim = C;
+      p.rope_cos = ctx->rope_cos; p.rope_sin = ctx->rope_sin; p.rope_len = S; p.rope_rows = M; p.rope_cols = C; p.rope_dim = C;
       CHKI(run_gemm(ctx, s, p));
     }
-    {
+    for (int n = 0; n < N; ++n) {
+      const int NkP = ceil32(Nk[n]);
       Flash256Params f;
       memset(&f, 0, sizeof(f));
-      f.q = ctx->t_q16; f.ldq = C; f.k = ctx->t_kall16 + l * 256; f.ldk = 1024;
-      f.vT = ctx->t_vTall16 + (size_t)l * 256 * NkP; f.ldvT = NkP;
-      f.Nq = S; f.Nk = Nk; f.splits = flash256_pick_splits(S, Nk); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
-      f.out = ctx->t_o16; f.ldout = C; f.scale_log2e = LOG2E / 16.f;
+      f.q = ctx->t_q16 + (size_t)n * S * C; f.ldq = C; f.k = ctx->t_kall16 + n * cap * 1024 + l * 256; f.ldk = 1024;
+      f.vT = ctx->t_vTall16 + n * cap * 1024 + (size_t)l * 256 * NkP; f.ldvT = NkP;
+      f.Nq = S; f.Nk = Nk[n]; f.splits = flash256_pick_splits(S, Nk[n]); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
+      f.out = ctx->t_o16 + (size_t)n * S * C; f.ldout = C; f.scale_log2e = LOG2E / 16.f;
       CHKI(run_flash256(ctx, s, f));
     }
     {
-      GemmParams p = lin_params(ctx->t_o16, C, S, L.cross_out);
+      GemmParams p = lin_params(ctx->t_o16, C, M, L.cross_out);
       p.res = x; p.ldres = C; p.out32 = x; p.ld32 = C;
       CHKI(run_gemm(ctx, s, p));
     }
     // ---- FFN
-    CHK(layernorm_launch(x, C, L.n3.w, L.n3.b, 1e-5f, S, C, ctx->t_h16, C, nullptr, 0, 0, s));
+    CHK(layernorm_launch(x, C, L.n3.w, L.n3.b, 1e-5f, M, C, ctx->t_h16, C, nullptr, 0, 0, s));
     {
-      GemmParams p = lin_params(ctx->t_h16, C, S, L.lin1);
+      GemmParams p = lin_params(ctx->t_h16, C, M, L.lin1);
       p.act = ACT_RELU; p.out16 = ctx->t_ff16; p.ld16 = 2048;
       CHKI(run_gemm(ctx, s, p));
-      GemmParams q = lin_params(ctx->t_ff16, 2048, S, L.lin2);
+      GemmParams q = lin_params(ctx->t_ff16, 2048, M, L.lin2);
       q.res = x; q.ldres = C; q.out32 = x; q.ld32 = C;
       CHKI(run_gemm(ctx, s, q));
     }
   }
-  CHK(layernorm_launch(x, C, ctx->ma_norm.w, ctx->ma_norm.b, 1e-5f, S, C, nullptr, 0, out32, C, 0, s));
+  CHK(layernorm_launch(x, C, ctx->ma_norm.w, ctx->ma_norm.b, 1e-5f, M, C, nullptr, 0, out32, C, 0, s));
   return 0;
 }
 

@@ -18,7 +18,7 @@ EXPORTS = [
     "sam2mi_abi_version", "sam2mi_create", "sam2mi_destroy", "sam2mi_last_error", "sam2mi_load_weight",
     "sam2mi_finalize_weights", "sam2mi_image_encoder", "sam2mi_set_image_e2e", "sam2mi_memory_attention",
     "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_dense_pe", "sam2mi_video_encode", "sam2mi_video_encode_u8", "sam2mi_fill_holes", "sam2mi_set_fill_hole_area",
-    "sam2mi_video_click", "sam2mi_video_mask", "sam2mi_image_predict", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_resize_bilinear",
+    "sam2mi_video_click", "sam2mi_video_mask", "sam2mi_image_predict", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_video_track_batch", "sam2mi_resize_bilinear",
     "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
     "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench",
 ]
@@ -304,6 +304,16 @@ class Engine:
                         C.c_void_p(mask_logits.data_ptr()) if mask_logits is not None else None)
         self._check(self.lib.sam2mi_video_track(self.h, self.stream, feat_slot, C.byref(sel), C.byref(pr) if pr is not None else None,
                                                 bank_slot, int(run_mem_encoder), C.byref(fo)), "sam2mi_video_track")
+
+    def video_track_batch(self, feat_slot: int, sels: Sequence[MemSelect], bank_slots: Sequence[int], run_mem_encoder: bool,
+                          outs: Sequence[dict]):
+        """Plain propagation of N (<= 8) objects on one frame in one pass; same results as N video_track calls."""
+        N = len(sels)
+        sel_arr = (MemSelect * N)(*sels)
+        slot_arr = (C.c_int32 * N)(*bank_slots)
+        fo_arr = (FrameOut * N)(*[self._frame_out(o) for o in outs])
+        self._check(self.lib.sam2mi_video_track_batch(self.h, self.stream, feat_slot, N, sel_arr, slot_arr, int(run_mem_encoder), fo_arr),
+                    "sam2mi_video_track_batch")
 
     # ------------------------------------------------------------------ profiling
     def profile_enable(self, on: bool):

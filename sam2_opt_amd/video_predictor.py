@@ -30,7 +30,7 @@ from .synthetic import normalize_frames
 
 class SAM2VideoPredictor:
     def __init__(self, model: str = "large", state_dict=None, ckpt_path: Optional[str] = None, device=None,
-                 encode_batch: int = 8, bank_slots: int = 96, fill_hole_area: int = 0, non_overlap_masks: bool = False,
+                 encode_batch: int = 8, bank_slots: int = 384, fill_hole_area: int = 0, non_overlap_masks: bool = False,
                  overlap_encode: bool = True):
         self.cfg = get_config(model)
         if state_dict is None and ckpt_path is not None:
@@ -51,6 +51,7 @@ class SAM2VideoPredictor:
         # The image encoder of the NEXT batch of frames runs on its own HIP stream beside the tracking of the current
         # batch: the tracking path is a chain of small latency-bound kernels (M = 4096 GEMMs, 8-token decoder ops) that
         # leaves most CUs idle, the encoder fills them.  The two paths share no workspace inside the engine.
+        self.object_batch = 8                       # objects per batched tracking pass (1: loop objects like the reference)
         self.overlap_encode = bool(overlap_encode)
         self._enc_stream = torch.cuda.Stream(device=self.device) if self.overlap_encode else None
         self.backend = "hip"
@@ -374,30 +375,44 @@ class SAM2VideoPredictor:
             end = min(start_frame_idx + max_frame_num_to_track, num_frames - 1)
             order = range(start_frame_idx, end + 1)
         for frame_idx in order:
-            per_obj = []
+            per_obj = [None] * len(st["obj_ids"])
+            todo = []                                          # objects to track on this frame (no stored conditioning output)
             for obj_idx in range(len(st["obj_ids"])):
                 od = st["output_dict_per_obj"][obj_idx]
                 if frame_idx in od["cond_frame_outputs"]:
-                    low = od["cond_frame_outputs"][frame_idx]["pred_masks"]
+                    per_obj[obj_idx] = od["cond_frame_outputs"][frame_idx]["pred_masks"]
                 else:
-                    feat = self._ensure_features(st, frame_idx, forward=not reverse)
-                    sel = self._select_memory(od, frame_idx, num_frames, reverse)
+                    todo.append(obj_idx)
+            if todo:
+                feat = self._ensure_features(st, frame_idx, forward=not reverse)
+            # the reference loops objects with B = 1 (:691-725); here up to 8 objects go through one batched pass
+            for c0 in range(0, len(todo), self.object_batch):
+                chunk = todo[c0:c0 + self.object_batch]
+                sels, slots, outs_l = [], [], []
+                for obj_idx in chunk:
+                    od = st["output_dict_per_obj"][obj_idx]
+                    sels.append(self._select_memory(od, frame_idx, num_frames, reverse))
                     self._free_bank(st, od["non_cond_frame_outputs"].pop(frame_idx, None))
-                    slot = self._alloc_bank(st)
-                    low = self.engine.new(1, 1, 256, 256)
-                    score = self.engine.new(1, 1)
-                    outs = dict(low_res_masks=low, object_score_logits=score)
+                    slots.append(self._alloc_bank(st))
+                    outs = dict(low_res_masks=self.engine.new(1, 1, 256, 256), object_score_logits=self.engine.new(1, 1))
                     if self.debug_trace is not None:
                         outs.update(pix_feat=self.engine.new(4096, 1, 256), ious=self.engine.new(1, 3), obj_ptr=self.engine.new(1, 256),
                                     low_res_multimasks=self.engine.new(1, 3, 256, 256),
                                     best_idx=self.engine.new(1, dtype=torch.int32))
-                        self.debug_trace[(obj_idx, frame_idx)] = dict(outs, L=sel.num_mem, P=4 * sel.num_ptr)
-                    self.engine.video_track(feat, sel, slot, True, outs)
-                    od["non_cond_frame_outputs"][frame_idx] = dict(slot=slot, pred_masks=low, object_score_logits=score,
-                                                                   has_mem=True, is_pts=False)
+                        self.debug_trace[(obj_idx, frame_idx)] = dict(outs, L=sels[-1].num_mem, P=4 * sels[-1].num_ptr)
+                    outs_l.append(outs)
+                if len(chunk) == 1:
+                    self.engine.video_track(feat, sels[0], slots[0], True, outs_l[0])
+                else:
+                    self.engine.video_track_batch(feat, sels, slots, True, outs_l)
+                for obj_idx, slot, outs in zip(chunk, slots, outs_l):
+                    od = st["output_dict_per_obj"][obj_idx]
+                    od["non_cond_frame_outputs"][frame_idx] = dict(slot=slot, pred_masks=outs["low_res_masks"],
+                                                                   object_score_logits=outs["object_score_logits"], has_mem=True, is_pts=False)
                     self._release_stale(st, od, frame_idx, reverse)
+                    per_obj[obj_idx] = outs["low_res_masks"]
+            for obj_idx in range(len(st["obj_ids"])):
                 st["frames_tracked_per_obj"][obj_idx][frame_idx] = {"reverse": reverse}
-                per_obj.append(low)
             low_all = torch.cat(per_obj, dim=0) if len(per_obj) > 1 else per_obj[0]
             yield frame_idx, st["obj_ids"], self._video_res(st, low_all)
 

@@ -198,3 +198,29 @@ def test_reverse_tracking_matches_reference_golden(predictor):
     assert order == list(g["order"])
     print(f"[parity] reverse tracking: worst rel-L2 {worst:.3e}", flush=True)
     predictor.reset_state(st)
+
+
+def test_object_batch_with_different_memory_lengths(predictor):
+    """Three objects through the batched tracking pass (sam2mi_video_track_batch), the third prompted on a later frame so its
+    memory bank / pointer list differs from the others on every frame: each object still equals its single-object run."""
+    from sam2_opt_amd.synthetic import synthetic_frames_u8
+    u8 = synthetic_frames_u8(seed=8, num_frames=6)
+    clicks = {1: (0, (512.0, 512.0)), 2: (0, (300.0, 700.0)), 3: (2, (760.0, 250.0))}
+
+    def run(obj_ids):
+        st = predictor.init_state(frames_u8=u8, video_height=1024, video_width=1024)
+        for oid in obj_ids:
+            t, xy = clicks[oid]
+            predictor.add_new_points_or_box(st, t, oid, points=np.array([xy], np.float32), labels=np.array([1], np.int32))
+        # start at frame 0 also for the object prompted on frame 2: the joint run tracks it there too (from its future
+        # conditioning frame), and those outputs are memories of the later frames
+        out = {t: vm.clone() for t, _, vm in predictor.propagate_in_video(st, start_frame_idx=0)}
+        predictor.reset_state(st)
+        return out
+    allo = run([1, 2, 3])
+    singles = {oid: run([oid]) for oid in (1, 2, 3)}
+    assert sorted(allo) == list(range(6))
+    for t, vm in allo.items():
+        assert vm.shape[0] == 3
+        for k, oid in enumerate((1, 2, 3)):
+            assert torch.equal(vm[k:k + 1], singles[oid][t]), (t, oid)
