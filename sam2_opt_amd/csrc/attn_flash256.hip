@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void flash256_kernel(const Flash256Params p
 //     owns (accumulator rows (r&3) + 8(r>>2) + 4 fh) are then exactly keys 16 ks + 8 fh + 0..7 in B-operand order, so
 //     the matching V^T fragment is ONE contiguous ds_read_b128 of the natural-order V^T row.
 //   * Keys past Nk (only in the last tile) are masked through the INITIAL accumulator (-1e30 instead of 0).
-constexpr int NST = 4;
+constexpr int NST_MAX = 4;       // ring stages: 4 (three tiles ahead, 133 KB) or 3 (two ahead, 100 KB: leaves LDS for a co-resident GEMM workgroup)
 // v3 LDS K image: piece kp (key rows 2kp, 2kp+1; 1 KiB) sits at kp * 1056: the 32-B pad rotates successive row pairs over
 // the 16 bank slots and the DMA source swaps the two 16-B halves of every 32 B in odd rows, so a 16-lane ds_read_b128
 // group (8 row pairs, one chunk) is conflict-free AND chunk 2 ks + fh of row r is at  base(r, fh) + 32 ks  - an
@@ -185,7 +185,7 @@ static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt
 // ABL != 0: timing ablations for tuning (results are wrong): 1 no LDS-DMA in the loop, 2 no barrier / vmcnt wait,
 // 3 no exponentials, 4 no P.V product, 5 no next-tile QK product
 // MASK: Nk is not a multiple of 32 (keys past Nk in the last tile are masked when the score chains are summed)
-template <int ABL, bool MASK>
+template <int ABL, bool MASK, int NST>
 __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -294,10 +294,9 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
   };
 
   if (n > 0) {
-    issue(0);
-    issue(1);
-    issue(2);
-    wait_vm<16>();
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) issue(t);
+    wait_vm<8 * (NST - 2)>();
     __builtin_amdgcn_s_barrier();
     f32x16 s;
     {
@@ -327,9 +326,9 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
 #pragma nounroll
       for (;;) {
         // here: s / tmax belong to tile i and tmax <= m_ref + RESCALE_THR on every lane
-        // tile i+1 landed (tile i+2 may stay in flight); every wave is past tile i-1 -> stage (i-1) % NST is free
+        // tile i+1 landed (with 4 stages tile i+2 may stay in flight); every wave is past tile i-1 -> stage (i-1) % NST is free
         if (ABL != 2) {
-          wait_vm<8>();
+          wait_vm<8 * (NST - 3)>();
           __builtin_amdgcn_s_barrier();
         }
         // next tile's scores (garbage past the last tile: never used) run beside this tile's exponentials
@@ -340,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
         __builtin_amdgcn_sched_barrier(0);
         // LDS-DMA pieces are expensive to issue (60+ cycles each): they go out one per pair of MFMAs instead of as a
         // burst behind the barrier, where the MFMA pipe would sit idle under them
-        if (ABL != 1) issue(i + 3);
+        if (ABL != 1) issue(i + NST - 1);
         f32x16 sa;
         qk_init(sa);
         if (ABL != 5) {
@@ -434,12 +433,13 @@ __global__ __launch_bounds__(256) void flash256_combine_kernel(const Flash256Par
 }  // namespace
 
 hipError_t flash256_init() {
-  const void* v3[7] = {reinterpret_cast<const void*>(&flash256_v3_kernel<0, false>), reinterpret_cast<const void*>(&flash256_v3_kernel<0, true>),
-                       reinterpret_cast<const void*>(&flash256_v3_kernel<1, true>), reinterpret_cast<const void*>(&flash256_v3_kernel<2, true>),
-                       reinterpret_cast<const void*>(&flash256_v3_kernel<3, true>), reinterpret_cast<const void*>(&flash256_v3_kernel<4, true>),
-                       reinterpret_cast<const void*>(&flash256_v3_kernel<5, true>)};
-  for (int i = 0; i < 7; ++i) {
-    hipError_t e = hipFuncSetAttribute(v3[i], hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE3_B);
+  const void* v3[9] = {reinterpret_cast<const void*>(&flash256_v3_kernel<0, false, 4>), reinterpret_cast<const void*>(&flash256_v3_kernel<0, true, 4>),
+                       reinterpret_cast<const void*>(&flash256_v3_kernel<0, false, 3>), reinterpret_cast<const void*>(&flash256_v3_kernel<0, true, 3>),
+                       reinterpret_cast<const void*>(&flash256_v3_kernel<1, true, 4>), reinterpret_cast<const void*>(&flash256_v3_kernel<2, true, 4>),
+                       reinterpret_cast<const void*>(&flash256_v3_kernel<3, true, 4>), reinterpret_cast<const void*>(&flash256_v3_kernel<4, true, 4>),
+                       reinterpret_cast<const void*>(&flash256_v3_kernel<5, true, 4>)};
+  for (int i = 0; i < 9; ++i) {
+    hipError_t e = hipFuncSetAttribute(v3[i], hipFuncAttributeMaxDynamicSharedMemorySize, NST_MAX * STAGE3_B);
     if (e != hipSuccess) return e;
   }
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&flash256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B);
@@ -462,16 +462,22 @@ hipError_t flash256_launch(const Flash256Params& p, hipStream_t stream) {
   else {
     static const int abl = getenv("SAM2MI_FLASH_ABL") ? atoi(getenv("SAM2MI_FLASH_ABL")) : 0;     // tuning only
     const dim3 grid((p.Nq / 128) * p.splits), block(256);
-    const size_t lds = NST * STAGE3_B;
+    static const int nst = getenv("SAM2MI_FLASH_STAGES") ? atoi(getenv("SAM2MI_FLASH_STAGES")) : 4;   // 3: 100 KB ring (tuning)
+    const size_t lds = (size_t)(nst == 3 ? 3 : 4) * STAGE3_B;
     switch (abl) {
-      case 1: flash256_v3_kernel<1, true><<<grid, block, lds, stream>>>(p); break;
-      case 2: flash256_v3_kernel<2, true><<<grid, block, lds, stream>>>(p); break;
-      case 3: flash256_v3_kernel<3, true><<<grid, block, lds, stream>>>(p); break;
-      case 4: flash256_v3_kernel<4, true><<<grid, block, lds, stream>>>(p); break;
-      case 5: flash256_v3_kernel<5, true><<<grid, block, lds, stream>>>(p); break;
+      case 1: flash256_v3_kernel<1, true, 4><<<grid, block, lds, stream>>>(p); break;
+      case 2: flash256_v3_kernel<2, true, 4><<<grid, block, lds, stream>>>(p); break;
+      case 3: flash256_v3_kernel<3, true, 4><<<grid, block, lds, stream>>>(p); break;
+      case 4: flash256_v3_kernel<4, true, 4><<<grid, block, lds, stream>>>(p); break;
+      case 5: flash256_v3_kernel<5, true, 4><<<grid, block, lds, stream>>>(p); break;
       default:
-        if (p.Nk % 32) flash256_v3_kernel<0, true><<<grid, block, lds, stream>>>(p);
-        else flash256_v3_kernel<0, false><<<grid, block, lds, stream>>>(p);
+        if (nst == 3) {
+          if (p.Nk % 32) flash256_v3_kernel<0, true, 3><<<grid, block, lds, stream>>>(p);
+          else flash256_v3_kernel<0, false, 3><<<grid, block, lds, stream>>>(p);
+        } else {
+          if (p.Nk % 32) flash256_v3_kernel<0, true, 4><<<grid, block, lds, stream>>>(p);
+          else flash256_v3_kernel<0, false, 4><<<grid, block, lds, stream>>>(p);
+        }
     }
   }
   hipError_t e = hipGetLastError();
