@@ -270,6 +270,62 @@ class SAM2VideoPredictor:
         td[key][frame_idx] = dict(slot=slot, pred_masks=low, object_score_logits=score, has_mem=False, is_pts=False)
         return frame_idx, st["obj_ids"], self._video_res(st, self._consolidated(st, frame_idx))
 
+    @torch.inference_mode()
+    def clear_all_prompts_in_frame(self, inference_state, frame_idx, obj_id, need_output=True):
+        """Remove all input points / mask of an object on a frame (sam2_video_predictor_official.py:739-779): the frame's
+        conditioning output, if any, is downgraded to a non-conditioning one."""
+        st = inference_state
+        obj_idx = self._obj_id_to_idx(st, obj_id)
+        st["point_inputs_per_obj"][obj_idx].pop(frame_idx, None)
+        st["mask_inputs_per_obj"][obj_idx].pop(frame_idx, None)
+        td, od = st["temp_output_dict_per_obj"][obj_idx], st["output_dict_per_obj"][obj_idx]
+        for key in ("cond_frame_outputs", "non_cond_frame_outputs"):
+            self._free_bank(st, td[key].pop(frame_idx, None))
+        out = od["cond_frame_outputs"].pop(frame_idx, None)
+        if out is not None:
+            self._free_bank(st, od["non_cond_frame_outputs"].get(frame_idx))
+            od["non_cond_frame_outputs"][frame_idx] = out
+            st["frames_tracked_per_obj"][obj_idx].pop(frame_idx, None)
+        if not need_output:
+            return None
+        return frame_idx, st["obj_ids"], self._video_res(st, self._consolidated(st, frame_idx))
+
+    @torch.inference_mode()
+    def remove_object(self, inference_state, obj_id, strict=False, need_output=True):
+        """Remove an object id from the tracking state (sam2_video_predictor_official.py:973-1060)."""
+        st = inference_state
+        old_idx = st["obj_id_to_idx"].get(obj_id)
+        updated = []
+        if old_idx is None:
+            if not strict:
+                return st["obj_ids"], updated
+            raise RuntimeError(f"Cannot remove object id {obj_id} as it doesn't exist. All existing object ids: {st['obj_ids']}.")
+        if len(st["obj_id_to_idx"]) == 1:
+            self.reset_state(st)
+            return st["obj_ids"], updated
+        input_frames = set(st["point_inputs_per_obj"][old_idx]) | set(st["mask_inputs_per_obj"][old_idx])
+        for t in input_frames:
+            self.clear_all_prompts_in_frame(st, t, obj_id, need_output=False)
+        # free the object's memory-bank slots, then re-index the per-object containers
+        for d in (st["output_dict_per_obj"][old_idx], st["temp_output_dict_per_obj"][old_idx]):
+            for key in ("cond_frame_outputs", "non_cond_frame_outputs"):
+                for out in d[key].values():
+                    self._free_bank(st, out)
+        old_ids = list(st["obj_ids"])
+        remain = [i for i in range(len(old_ids)) if i != old_idx]
+        new_ids = [old_ids[i] for i in remain]
+        remap = {o: n for n, o in enumerate(remain)}
+        st["obj_id_to_idx"] = OrderedDict((oid, i) for i, oid in enumerate(new_ids))
+        st["obj_idx_to_id"] = OrderedDict((i, oid) for i, oid in enumerate(new_ids))
+        st["obj_ids"] = new_ids
+        for name in ("point_inputs_per_obj", "mask_inputs_per_obj", "output_dict_per_obj", "temp_output_dict_per_obj", "frames_tracked_per_obj"):
+            c = st[name]
+            st[name] = type(c)((remap[k], v) for k, v in c.items() if k in remap)
+        if need_output:
+            for t in sorted(input_frames):
+                updated.append((t, self._video_res(st, self._consolidated(st, t))))
+        return st["obj_ids"], updated
+
     def _consolidated(self, st, frame_idx):
         """(num_obj,1,256,256) low-res logits on `frame_idx`; objects without output get NO_OBJ_SCORE (:525-570)."""
         outs = []

@@ -224,3 +224,30 @@ def test_object_batch_with_different_memory_lengths(predictor):
         assert vm.shape[0] == 3
         for k, oid in enumerate((1, 2, 3)):
             assert torch.equal(vm[k:k + 1], singles[oid][t]), (t, oid)
+
+
+def test_remove_object_and_clear_prompts(predictor):
+    """Host-side state handling of remove_object / clear_all_prompts_in_frame (sam2_video_predictor_official.py:739-779,
+    :973-1060): after removing one of two objects the other tracks exactly as if it had been alone; clearing the only
+    prompt of an object leaves it without conditioning frames."""
+    from sam2_opt_amd.synthetic import synthetic_frames_u8
+    u8 = synthetic_frames_u8(seed=9, num_frames=4)
+    st = predictor.init_state(frames_u8=u8, video_height=1024, video_width=1024)
+    predictor.add_new_points_or_box(st, 0, 7, points=np.array([[512.0, 512.0]], np.float32), labels=np.array([1], np.int32))
+    predictor.add_new_points_or_box(st, 0, 9, points=np.array([[300.0, 700.0]], np.float32), labels=np.array([1], np.int32))
+    both = [vm.clone() for _, _, vm in predictor.propagate_in_video(st)]
+    ids, upd = predictor.remove_object(st, 7)
+    assert list(ids) == [9] and [t for t, _ in upd] == [0]
+    assert predictor.remove_object(st, 12345) == ([9], [])
+    with pytest.raises(RuntimeError):
+        predictor.remove_object(st, 12345, strict=True)
+    alone = [vm.clone() for _, ids2, vm in predictor.propagate_in_video(st)]
+    assert len(alone) == 4
+    for a, b in zip(alone, both):
+        assert a.shape[0] == 1 and torch.equal(a, b[1:2])
+    free_before = len(st["free_bank_slots"])
+    _, ids3, vm = predictor.clear_all_prompts_in_frame(st, 0, 9)
+    assert list(ids3) == [9] and len(st["free_bank_slots"]) >= free_before
+    with pytest.raises(RuntimeError):                       # no conditioning frame left for object 9
+        next(predictor.propagate_in_video(st))
+    predictor.reset_state(st)
