@@ -2,7 +2,11 @@
 // of RoPEAttention, /root/reference/sam2/sam2/modeling/sam/transformer.py:345-424: 1 head, d=256,
 // q = 4096 tokens, kv = 4096 (self) or L*4096+P <= 28736 (memory bank + object pointers)).
 //
-// 4096 queries are only 128 wave tiles, so the KV axis is split across workgroups (grid.y) and a
+// The production kernel is flash256_v3_kernel further down (one wave per SIMD, 3-4 stage LDS-DMA ring, cross-tile
+// software pipeline, deferred rescale); flash256_kernel right below is the earlier 2-waves-per-SIMD version, kept
+// behind SAM2MI_FLASH_V2 for A/B runs.  Common structure:
+//
+// 4096 queries are only 128 wave tiles, so the KV axis is split across workgroups and a
 // combine pass merges the partial (m, l, O).  Workgroup = 4 waves = 128 queries; the 4 waves share
 // each 32-key K tile and V^T tile through LDS.  Per wave: S^T = K.Q^T (16 MFMA k-steps over d),
 // in-register online softmax (column = query on the lane), O^T += V^T.P^T with P^T taken straight

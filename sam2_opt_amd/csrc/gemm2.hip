@@ -6,9 +6,11 @@
 //     (LDS-DMA destinations are lane-linear): LDS 16-B slot `pc` of row r holds logical chunk
 //     pc ^ ((r >> 1) & 7).  The ds_read_b128 fragment reads apply the same XOR, which spreads every
 //     16-lane read group over all 16 slots of the 256-B bank row (conflict-free).
-//   * Pipeline: tile t+1 is in flight (LDS-DMA) while tile t is consumed from LDS; the compiler's
-//     vmcnt(0) in front of __syncthreads() retires it ("2-phase minimum" structure of the CDNA guide).
-//   * K may be any multiple of 16: the last K tile runs fewer 16-deep MFMA steps.
+//   * Pipeline: tile t+1 is in flight (LDS-DMA, wave-uniform scalar base + one 32-bit per-lane offset per piece) while
+//     tile t is consumed from LDS; a counted vmcnt + raw s_barrier per K tile (STAGES - 1 tiles stay in flight).  The K loop
+//     has ONE straight-line MFMA path with the fragments of k-step s+1 read while the MFMAs of step s run.
+//   * K may be any multiple of 16: a K tail is peeled behind the loop (last tile loaded from columns [K-64, K)).
+//   * Workgroups of 8 waves (128x128 or 128x64 tile, 2-3 per CU) on the large shapes, 4 waves (64x64) on M = 4096.
 //   * Epilogue: each 32x32 accumulator tile goes through a wave-private 4-KiB LDS patch so that residual
 //     loads and f32/f16 stores are 16-B / 8-B per lane over whole 128-B row segments (the accumulator layout
 //     itself has one column per lane); transposed outputs are stored straight from the accumulators
