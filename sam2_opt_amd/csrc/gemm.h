@@ -42,3 +42,6 @@ hipError_t gemm_v2_init();
 // gemm3.hip: persistent loader/consumer kernel (large M*N, K % 16 == 0)
 hipError_t gemm_v3_launch(const GemmParams& p, hipStream_t stream);
 hipError_t gemm_v3_init();
+// gemm4.hip: 256x256 staggered 4-phase kernel, one workgroup per CU (experimental; K % 64 == 0)
+hipError_t gemm_p4_launch(const GemmParams& p, hipStream_t stream);
+hipError_t gemm_p4_init();

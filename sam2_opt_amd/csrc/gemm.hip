@@ -201,7 +201,9 @@ hipError_t gemm_init() {
   for (int i = 0; i < 9; ++i)
     if (e[i] != hipSuccess) return e[i];
   hipError_t e2 = gemm_v2_init();
-  return e2 != hipSuccess ? e2 : gemm_v3_init();
+  if (e2 != hipSuccess) return e2;
+  hipError_t e3 = gemm_v3_init();
+  return e3 != hipSuccess ? e3 : gemm_p4_init();
 }
 
 template <int BK>

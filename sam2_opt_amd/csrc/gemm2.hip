@@ -311,6 +311,7 @@ static inline long tiles_of(const GemmParams& p, int bm, int bn) { return (long)
 hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   const int force = p.tile_hint;
   if (force == 6) return gemm_v3_launch(p, s);
+  if (force == 20 && (p.K & 63) == 0) return gemm_p4_launch(p, s);          // experimental 256x256 staggered kernel (else: automatic)
   if (force == 2) return v2_launch<256, 128, 4, 2, 3>(p, s);
   if (force == 3) return v2_launch<128, 128, 2, 2, 2>(p, s);
   if (force == 7) return v2_launch<128, 64, 2, 2, 3>(p, s);
