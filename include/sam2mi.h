@@ -192,6 +192,9 @@ int sam2mi_profile_enable(sam2mi_ctx* ctx, int on);
 int sam2mi_profile_read(sam2mi_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches,
                         double* attn_ms, double* attn_flops, int64_t* attn_launches);
 
+/* Same for the fused Hiera MLP kernel (mlp_fused_kernel: fc1 + GELU + fc2 + residual; flops = 2 * 2 * M * C * 4C per launch). */
+int sam2mi_profile_read_mlp(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* launches);
+
 /* Debug/test entry points: single kernels behind the C ABI (used by tests/test_kernels_gpu.py). */
 int sam2mi_debug_gemm(sam2mi_ctx* ctx, void* stream, const float* A, const float* W, const float* bias, int M, int N, int K,
                       int act, const float* residual, float* out);
@@ -199,6 +202,10 @@ int sam2mi_debug_hiera_attention(sam2mi_ctx* ctx, void* stream, const float* q, 
                                  int heads, int GQ, int GK, int wq, int wk, float* out);
 int sam2mi_debug_flash256(sam2mi_ctx* ctx, void* stream, const float* q, const float* k, const float* v, int Nq, int Nk, float* out);
 int sam2mi_debug_hiera_block(sam2mi_ctx* ctx, void* stream, int block_idx, const float* x_nhwc, int B, float* out_nhwc);
+/* Hiera MLP x += fc2(GELU(fc1(xn))) on its own (f32 in, f16 MFMA operands): fused kernel (fused != 0) or the two-GEMM path;
+ * iters > 0 also times that many launches (ms per launch).  MultiScaleBlock.forward, modeling/backbones/hieradet.py:163-165. */
+int sam2mi_debug_mlp(sam2mi_ctx* ctx, void* stream, const float* xn, const float* W1, const float* b1, const float* W2,
+                     const float* b2, float* x, int M, int C, int fused, int iters, float* ms_out);
 int sam2mi_debug_gemm_bench(sam2mi_ctx* ctx, void* stream, int M, int N, int K, int iters, int mode, float* ms_out);
 /* time `iters` launches of the d=256 flash attention (+ combine) on random f16 operands; ms per launch */
 int sam2mi_debug_flash_bench(sam2mi_ctx* ctx, void* stream, int Nq, int Nk, int iters, float* ms_out);

@@ -11,6 +11,7 @@
 #include "attn.h"
 #include "gemm.h"
 #include "kernels.h"
+#include "mlp_fused.h"
 
 struct HostW {
   std::vector<float> data;
@@ -174,7 +175,8 @@ struct sam2mi_ctx {
 
   // ---- profiling
   bool prof_on = false;
-  ProfAcc prof_gemm, prof_attn;
+  ProfAcc prof_gemm, prof_attn, prof_mlp;
+  bool use_fused_mlp = true;       // stages with C <= 288: one fused fc1-GELU-fc2 kernel (SAM2MI_NO_FUSED_MLP=1: two GEMMs, for A/B runs)
 };
 
 int sam2mi_set_error(sam2mi_ctx* ctx, const char* what, const char* detail);
@@ -193,6 +195,7 @@ int sam2mi_set_error(sam2mi_ctx* ctx, const char* what, const char* detail);
 void* dalloc(sam2mi_ctx* ctx, size_t bytes);
 int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p);                 // with profiling
 int run_hiera_attn(sam2mi_ctx* ctx, hipStream_t s, const HieraAttnParams& p);
+int run_mlp_fused(sam2mi_ctx* ctx, hipStream_t s, const MlpFusedParams& p, int C);     // with profiling
 int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p);
 GemmParams lin_params(const half_t* A, int lda, int M, const Lin16& L);            // bias + W filled, n_split = N
 

@@ -1,5 +1,6 @@
 // Context, weight packing, input-independent tables and profiled launch wrappers.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "engine.h"
@@ -67,6 +68,13 @@ int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p) {
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_gemm, s, e0, e1);
   CHK(gemm_launch(p, s));
   if (ctx->prof_on) prof_end(ctx->prof_gemm, s, e0, e1, 2.0 * p.M * (double)p.N * p.K);
+  return 0;
+}
+int run_mlp_fused(sam2mi_ctx* ctx, hipStream_t s, const MlpFusedParams& p, int C) {
+  hipEvent_t e0, e1;
+  if (ctx->prof_on) prof_begin(ctx, ctx->prof_mlp, s, e0, e1);
+  CHK(mlp_fused_launch(p, C, s));
+  if (ctx->prof_on) prof_end(ctx->prof_mlp, s, e0, e1, 2.0 * 2.0 * p.M * (double)C * (4.0 * C));   // fc1 + fc2
   return 0;
 }
 int run_hiera_attn(sam2mi_ctx* ctx, hipStream_t s, const HieraAttnParams& p) {
@@ -237,8 +245,10 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   if (ctx->cfg.max_batch <= 0) ctx->cfg.max_batch = 1;
   if (ctx->cfg.bank_slots <= 0) ctx->cfg.bank_slots = 64;
   if (ctx->cfg.feat_slots <= 0) ctx->cfg.feat_slots = 16;
+  ctx->use_fused_mlp = getenv("SAM2MI_NO_FUSED_MLP") == nullptr;
   hipError_t e = gemm_init();
   if (e == hipSuccess) e = flash256_init();
+  if (e == hipSuccess) e = mlp_fused_init();
   if (e != hipSuccess) {
     sam2mi_set_error(nullptr, "gemm_init", hipGetErrorString(e));
     delete ctx;
@@ -252,7 +262,7 @@ extern "C" void sam2mi_destroy(sam2mi_ctx* ctx) {
   if (!ctx) return;
   hipDeviceSynchronize();
   for (void* p : ctx->allocs) hipFree(p);
-  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn}) {
+  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp}) {
     for (auto& pr : a->pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto& pr : a->pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   }
@@ -278,14 +288,14 @@ extern "C" int sam2mi_load_weight(sam2mi_ctx* ctx, const char* key, const float*
 extern "C" int sam2mi_profile_enable(sam2mi_ctx* ctx, int on) {
   ctx->prof_on = on != 0;
   if (on) {
-    for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn}) { a->ms = 0; a->flops = 0; a->launches = 0; }
+    for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp}) { a->ms = 0; a->flops = 0; a->launches = 0; }
   }
   return 0;
 }
 
 extern "C" int sam2mi_profile_read(sam2mi_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches,
                                    double* attn_ms, double* attn_flops, int64_t* attn_launches) {
-  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn}) {
+  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp}) {
     for (auto& pr : a->pending) {
       hipEventSynchronize(pr.second);
       float ms = 0;
@@ -301,6 +311,23 @@ extern "C" int sam2mi_profile_read(sam2mi_ctx* ctx, double* gemm_ms, double* gem
   if (attn_ms) *attn_ms = ctx->prof_attn.ms;
   if (attn_flops) *attn_flops = ctx->prof_attn.flops;
   if (attn_launches) *attn_launches = ctx->prof_attn.launches;
+  return 0;
+}
+
+extern "C" int sam2mi_profile_read_mlp(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* launches) {
+  if (!ctx) return 1;
+  ProfAcc& a = ctx->prof_mlp;
+  for (auto& pr : a.pending) {
+    hipEventSynchronize(pr.second);
+    float t = 0;
+    hipEventElapsedTime(&t, pr.first, pr.second);
+    a.ms += t;
+    a.pool.push_back(pr);
+  }
+  a.pending.clear();
+  if (ms) *ms = a.ms;
+  if (flops) *flops = a.flops;
+  if (launches) *launches = a.launches;
   return 0;
 }
 

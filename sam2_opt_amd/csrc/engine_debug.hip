@@ -138,6 +138,62 @@ extern "C" int sam2mi_debug_read(sam2mi_ctx* ctx, void* stream, const char* name
   return 0;
 }
 
+// Hiera MLP on its own:  x += fc2(GELU(fc1(xn)))  with xn [M,C], W1 [4C,C], W2 [C,4C] f32 (rounded to f16 here), x [M,C] f32 in/out.
+// fused != 0: mlp_fused_kernel; 0: the two-GEMM path (fc1 + GELU epilogue -> f16 hidden -> fc2 + residual epilogue).
+// iters > 0 additionally times that many launches on a scratch copy of x (ms per launch in *ms_out).
+extern "C" int sam2mi_debug_mlp(sam2mi_ctx* ctx, void* stream, const float* xn, const float* W1, const float* b1, const float* W2,
+                                const float* b2, float* x, int M, int C, int fused, int iters, float* ms_out) {
+  if (!ctx) return 1;
+  if (fused && !mlp_fused_supported(C)) return sam2mi_set_error(ctx, __func__, "fused MLP supports C = 144 / 288");
+  hipStream_t s = (hipStream_t)stream;
+  const int H4 = 4 * C;
+  Tmp t;
+  half_t* x16 = t.get<half_t>((size_t)M * C);
+  half_t* w1 = t.get<half_t>((size_t)H4 * C);
+  half_t* w2 = t.get<half_t>((size_t)C * H4);
+  half_t* h16 = fused ? nullptr : t.get<half_t>((size_t)M * H4);
+  float* xs = iters > 0 ? t.get<float>((size_t)M * C) : nullptr;
+  if (!x16 || !w1 || !w2 || (!fused && !h16) || (iters > 0 && !xs)) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+  CHK(cast_add_launch(xn, C, nullptr, 0, 0, 0.f, M, C, x16, C, nullptr, 0, s));
+  CHK(cast_add_launch(W1, C, nullptr, 0, 0, 0.f, H4, C, w1, C, nullptr, 0, s));
+  CHK(cast_add_launch(W2, H4, nullptr, 0, 0, 0.f, C, H4, w2, H4, nullptr, 0, s));
+  auto run = [&](float* xio) -> int {
+    if (fused) {
+      MlpFusedParams m{x16, C, w1, b1, w2, b2, xio, C, M};
+      CHK(mlp_fused_launch(m, C, s));
+    } else {
+      GemmParams p = gemm_params_zero();
+      p.A = x16; p.lda = C; p.W = w1; p.ldw = C; p.M = M; p.N = H4; p.K = C; p.n_split = H4; p.bias = b1; p.act = ACT_GELU;
+      p.out16 = h16; p.ld16 = H4;
+      CHK(gemm_launch(p, s));
+      GemmParams q = gemm_params_zero();
+      q.A = h16; q.lda = H4; q.W = w2; q.ldw = H4; q.M = M; q.N = C; q.K = H4; q.n_split = C; q.bias = b2;
+      q.res = xio; q.ldres = C; q.out32 = xio; q.ld32 = C;
+      CHK(gemm_launch(q, s));
+    }
+    return 0;
+  };
+  if (iters > 0) {
+    CHK(hipMemcpyAsync(xs, x, (size_t)M * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int i = 0; i < 2; ++i) CHKI(run(xs));
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0));
+    CHK(hipEventCreate(&e1));
+    CHK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) CHKI(run(xs));
+    CHK(hipEventRecord(e1, s));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms / iters;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+  }
+  CHKI(run(x));
+  CHK(hipStreamSynchronize(s));
+  return 0;
+}
+
 // time `iters` launches of the production GEMM on an [M,K] x [N,K]^T problem (random f16 operands); returns ms per launch
 extern "C" int sam2mi_debug_gemm_bench(sam2mi_ctx* ctx, void* stream, int M, int N, int K, int iters, int mode, float* ms_out) {
   const int tile_hint = mode >> 4;
@@ -164,6 +220,7 @@ extern "C" int sam2mi_debug_gemm_bench(sam2mi_ctx* ctx, void* stream, int M, int
   if (getenv("SAM2MI_BENCH_NOMEM")) { p.lda = 0; p.ldw = 0; }   // tuning aid: every tile reads the same rows (cache-resident operands)
   if (mode == 0) { p.out16 = o16; p.ld16 = N; }            // f16 output (QKV / fc1 style)
   else if (mode == 1) { p.out32 = o32; p.ld32 = N; p.res = o32; p.ldres = N; }   // f32 in-place residual (proj / fc2 style)
+  else if (mode == 3) { p.out16 = o16; p.ld16 = N; p.act = ACT_GELU; }          // f16 output through GELU (fc1 style)
   // mode 2: no output at all (main-loop-only timing, tuning aid)
   for (int i = 0; i < 3; ++i) CHK(gemm_launch(p, s));
   hipEvent_t e0, e1;

@@ -27,13 +27,17 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 template <int BM, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_v2_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8) ? 1 : 2) void gemm_v2_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   constexpr int A_CALLS = BM / 8 / NW, B_CALLS = BN / 8 / NW;     // 1-KiB pieces per wave
-  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over the waves");
+  // EVEN: A and B pieces split evenly over the waves.  Otherwise (12-wave 256x192 workgroup) the PA + PB pieces of a K
+  // tile are dealt round-robin, piece q = wave + j * NW (A pieces first); STAGES == 2 only (vmcnt is always drained to 0).
+  constexpr bool EVEN = (BM / 8) % NW == 0 && (BN / 8) % NW == 0;
+  constexpr int PA = BM / 8, PB = BN / 8, NJ = (PA + PB + NW - 1) / NW;
+  static_assert(EVEN || STAGES == 2, "uneven piece split needs the 2-stage ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -61,17 +65,29 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_v2_kernel(const GemmPara
   // last (K % 64) / 16 k-steps are consumed.  K < 64 (one partial tile): chunks past K are redirected to column 0.
   const char* baseA = reinterpret_cast<const char*>(p.A + (size_t)m0 * p.lda);
   const char* baseB = reinterpret_cast<const char*>(p.W + (size_t)n0 * p.ldw);
-  unsigned a_off[A_CALLS], b_off[B_CALLS];
+  unsigned a_off[EVEN ? A_CALLS : 1], b_off[EVEN ? B_CALLS : 1], g_off[EVEN ? 1 : NJ];
   const bool short_k = p.K < 64;
+  if constexpr (!EVEN) {
 #pragma unroll
-  for (int j = 0; j < A_CALLS; ++j) {
+    for (int j = 0; j < NJ; ++j) {
+      const int q = wave + j * NW;                                 // wave-uniform
+      const bool isA = q < PA;
+      const int row = (isA ? q : q - PA) * 8 + srow;
+      int kc = (spc ^ ((row >> 1) & 7)) << 3;
+      if (short_k && kc >= p.K) kc = 0;
+      g_off[j] = isA ? (unsigned)((min(m0 + row, p.M - 1) - m0) * p.lda + kc) * 2u
+                     : (unsigned)((min(n0 + row, p.N - 1) - n0) * p.ldw + kc) * 2u;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < (EVEN ? A_CALLS : 0); ++j) {
     const int row = (wave * A_CALLS + j) * 8 + srow;
     int kc = (spc ^ ((row >> 1) & 7)) << 3;
     if (short_k && kc >= p.K) kc = 0;
     a_off[j] = (unsigned)((min(m0 + row, p.M - 1) - m0) * p.lda + kc) * 2u;
   }
 #pragma unroll
-  for (int j = 0; j < B_CALLS; ++j) {
+  for (int j = 0; j < (EVEN ? B_CALLS : 0); ++j) {
     const int row = (wave * B_CALLS + j) * 8 + srow;
     int kc = (spc ^ ((row >> 1) & 7)) << 3;
     if (short_k && kc >= p.K) kc = 0;
@@ -83,12 +99,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_v2_kernel(const GemmPara
     const int kcol = (k_tail && kt == nk - 1) ? p.K - 64 : kt * 64;       // scalar
     const char* ka = baseA + (size_t)kcol * 2;
     const char* kb = baseB + (size_t)kcol * 2;
+    if constexpr (EVEN) {
 #pragma unroll
-    for (int j = 0; j < A_CALLS; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ka + a_off[j]), (lds_ptr_t)(sbase + (wave * A_CALLS + j) * 1024), 16, 0, 0);
+      for (int j = 0; j < A_CALLS; ++j)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ka + a_off[j]), (lds_ptr_t)(sbase + (wave * A_CALLS + j) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < B_CALLS; ++j)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + b_off[j]), (lds_ptr_t)(sbase + A_BYTES + (wave * B_CALLS + j) * 1024), 16, 0, 0);
+      for (int j = 0; j < B_CALLS; ++j)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + b_off[j]), (lds_ptr_t)(sbase + A_BYTES + (wave * B_CALLS + j) * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int q = wave + j * NW;
+        if ((j + 1) * NW <= PA + PB || q < PA + PB)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)((q < PA ? ka : kb) + g_off[j]), (lds_ptr_t)(sbase + q * 1024), 16, 0, 0);
+      }
+    }
   };
 
   // ---- K pipeline: STAGES-1 tiles in flight, counted vmcnt + raw barrier (a __syncthreads() would drain the DMA queue)
@@ -187,7 +212,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_v2_kernel(const GemmPara
             x = (n & 1) ? (partner * sn + x * c) : (x * c - partner * sn);
           }
         }
-        if (p.act == ACT_GELU) x = gelu_erf(x);
+        if (p.act == ACT_GELU) x = gelu_erf_fast(x);
         else if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
         else if (p.act == ACT_SIGMOID) x = 1.f / (1.f + __expf(-x));
         v[r] = x * cscale;
@@ -289,10 +314,10 @@ hipError_t v2_attr() {
 }  // namespace
 
 hipError_t gemm_v2_init() {
-  hipError_t e[11] = {v2_attr<256, 128, 4, 2, 3>(), v2_attr<128, 128, 2, 2, 2>(), v2_attr<128, 64, 2, 2, 2>(), v2_attr<64, 64, 2, 2, 2>(),
+  hipError_t e[13] = {v2_attr<256, 256, 4, 4, 2>(), v2_attr<256, 192, 4, 3, 2>(), v2_attr<256, 128, 4, 2, 3>(), v2_attr<128, 128, 2, 2, 2>(), v2_attr<128, 64, 2, 2, 2>(), v2_attr<64, 64, 2, 2, 2>(),
                       v2_attr<128, 64, 2, 2, 3>(), v2_attr<128, 128, 2, 2, 3>(), v2_attr<64, 64, 2, 2, 4>(),
                       v2_attr<128, 128, 4, 2, 2>(), v2_attr<256, 128, 4, 2, 2>(), v2_attr<256, 64, 4, 2, 2>(), v2_attr<128, 64, 4, 2, 2>()};
-  for (int i = 0; i < 11; ++i)
+  for (int i = 0; i < 13; ++i)
     if (e[i] != hipSuccess) return e[i];
   return hipSuccess;
 }
@@ -321,6 +346,8 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   if (force == 11) return v2_launch<256, 128, 4, 2, 2>(p, s);
   if (force == 12) return v2_launch<256, 64, 4, 2, 2>(p, s);
   if (force == 13) return v2_launch<128, 64, 4, 2, 2>(p, s);
+  if (force == 14) return v2_launch<256, 256, 4, 4, 2>(p, s);
+  if (force == 15) return v2_launch<256, 192, 4, 3, 2>(p, s);
   if (force == 4) return v2_launch<128, 64, 2, 2, 2>(p, s);
   if (force == 5) return v2_launch<64, 64, 2, 2, 2>(p, s);
   const int n128 = ((p.N + 127) / 128) * 128;

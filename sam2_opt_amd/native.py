@@ -19,8 +19,8 @@ EXPORTS = [
     "sam2mi_finalize_weights", "sam2mi_image_encoder", "sam2mi_set_image_e2e", "sam2mi_memory_attention",
     "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_dense_pe", "sam2mi_video_encode", "sam2mi_video_encode_u8", "sam2mi_fill_holes", "sam2mi_set_fill_hole_area",
     "sam2mi_video_click", "sam2mi_video_mask", "sam2mi_image_predict", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_video_track_batch", "sam2mi_resize_bilinear",
-    "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
-    "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench",
+    "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_profile_read_mlp", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
+    "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench", "sam2mi_debug_mlp",
 ]
 
 
@@ -322,8 +322,11 @@ class Engine:
     def profile_read(self) -> dict:
         v = [C.c_double(), C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_int64()]
         self._check(self.lib.sam2mi_profile_read(self.h, *[C.byref(x) for x in v]), "sam2mi_profile_read")
+        m = [C.c_double(), C.c_double(), C.c_int64()]
+        self._check(self.lib.sam2mi_profile_read_mlp(self.h, *[C.byref(x) for x in m]), "sam2mi_profile_read_mlp")
         return dict(gemm_ms=v[0].value, gemm_flops=v[1].value, gemm_launches=v[2].value, attn_ms=v[3].value,
-                    attn_flops=v[4].value, attn_launches=v[5].value)
+                    attn_flops=v[4].value, attn_launches=v[5].value, mlp_ms=m[0].value, mlp_flops=m[1].value,
+                    mlp_launches=m[2].value)
 
     # ------------------------------------------------------------------ single-kernel debug entry points (tests)
     def debug_gemm(self, A, W, bias=None, act=0, residual=None, tile_hint=0):
@@ -363,6 +366,16 @@ class Engine:
         ms = C.c_float()
         self._check(self.lib.sam2mi_debug_flash_bench(self.h, self.stream, Nq, Nk, iters, C.byref(ms)), "sam2mi_debug_flash_bench")
         return ms.value
+
+    def debug_mlp(self, xn, W1, b1, W2, b2, x, fused=True, iters=0):
+        """x + fc2(GELU(fc1(xn))) through the fused MLP kernel (or the two-GEMM path); returns (out, ms per launch or None)."""
+        M, Cc = xn.shape
+        out = x.clone().contiguous()
+        ms = C.c_float()
+        self._check(self.lib.sam2mi_debug_mlp(self.h, self.stream, _ptr(xn.contiguous()), _ptr(W1.contiguous()), _ptr(b1.contiguous()),
+                                              _ptr(W2.contiguous()), _ptr(b2.contiguous()), _ptr(out), M, Cc, int(fused), int(iters),
+                                              C.byref(ms)), "sam2mi_debug_mlp")
+        return out, (ms.value if iters > 0 else None)
 
     def debug_gemm_bench(self, M, N, K, iters=20, mode=0) -> float:
         ms = C.c_float()

@@ -27,7 +27,7 @@ def r16(x):
     (300, 200, 144, 0, False), (4096, 1728, 576, 0, False), (16384, 432, 144, 1, True), (8, 256, 256, 2, False),
     (1000, 64, 160, 0, True), (4096, 4, 32, 0, False), (129, 65, 2304, 1, True), (4096, 576, 2304, 0, True),
 ])
-@pytest.mark.parametrize("hint", [0, 2, 5, 6, 10, 13, 20])   # automatic, 256x128, 64x64, persistent v3, 8-wave 128x128 / 128x64, 256x256 staggered (K % 64 == 0)
+@pytest.mark.parametrize("hint", [0, 2, 5, 6, 10, 13, 14, 15, 20])   # automatic (14: 16-wave 256x256, 15: 12-wave 256x192), 256x128, 64x64, persistent v3, 8-wave 128x128 / 128x64, 256x256 staggered (K % 64 == 0)
 def test_gemm(eng, M, N, K, act, res, hint):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
     A = r16(torch.randn(M, K, generator=g)).cuda()
@@ -91,3 +91,23 @@ def test_flash256(eng, Nq, Nk):
     s = (q.double() @ k.double().t()) / 16.0
     ref = (torch.softmax(s, -1) @ v.double()).float()
     check(f"flash256 {Nq}x{Nk}", out, ref, 4e-3, 2e-3)
+
+
+@pytest.mark.parametrize("M,C", [(256, 144), (1000, 144), (128, 288), (777, 288), (8192, 144), (4096, 288)])
+def test_mlp_fused(eng, M, C):
+    """Fused fc1-GELU-fc2-residual kernel (stages 1-2 of Hiera, hieradet.py:163-165) vs fp64 PyTorch on f16-rounded operands
+    (the hidden activation is rounded to f16 between the two products, exactly as the two-GEMM path stores it) and vs
+    that two-GEMM path."""
+    g = torch.Generator(device="cpu").manual_seed(M + C)
+    xn = r16(torch.randn(M, C, generator=g)).cuda()
+    W1 = r16(torch.randn(4 * C, C, generator=g) / math.sqrt(C)).cuda()
+    b1 = (0.3 * torch.randn(4 * C, generator=g)).cuda()
+    W2 = r16(torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)).cuda()
+    b2 = (0.3 * torch.randn(C, generator=g)).cuda()
+    x = torch.randn(M, C, generator=g).cuda()
+    out, _ = eng.debug_mlp(xn, W1, b1, W2, b2, x, fused=True)
+    h = F.gelu(xn.double() @ W1.double().t() + b1.double()).half().double()
+    ref = x.double() + h @ W2.double().t() + b2.double()
+    check(f"mlp_fused {M}x{C}", out, ref.float(), 1e-4, 2e-4)
+    two, _ = eng.debug_mlp(xn, W1, b1, W2, b2, x, fused=False)
+    check(f"mlp_fused vs two-GEMM {M}x{C}", out, two, 1e-4, 2e-4)
