@@ -39,6 +39,7 @@ struct HieraBlockW {
   bool q_pool, stage_end;
   Norm n1, n2;
   Lin16 qkv, proj, fc1, fc2, sc;   // sc: dim-change shortcut projection (blocks 2, 8, 44)
+  half_t* mlp_pack = nullptr;      // fc1 + fc2 in the fused MLP kernel's piece order (dim_out <= 288), mlp_fused_pack
   float* qscale = nullptr;         // [3*dim_out] column scale of the QKV GEMM: q columns *= 72^-0.5*log2(e), k/v columns 1
 };
 

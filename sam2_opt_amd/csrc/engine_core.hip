@@ -377,6 +377,10 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
       b.proj = pk.lin16(p + "attn.proj");
       b.fc1 = pk.lin16(p + "mlp.layers.0");
       b.fc2 = pk.lin16(p + "mlp.layers.1");
+      if (pk.ok && mlp_fused_supported(b.dim_out)) {     // stages 1-2: weights also in the fused MLP kernel's piece order
+        b.mlp_pack = (half_t*)dalloc(ctx, mlp_fused_pack_bytes(b.dim_out));
+        if (!b.mlp_pack || mlp_fused_pack(b.fc1.w, b.fc2.w, b.dim_out, b.mlp_pack, nullptr) != hipSuccess) pk.ok = false;
+      }
       if (dim != dim_out) b.sc = pk.lin16(p + "proj");
       {
         std::vector<float> qs((size_t)3 * dim_out, 1.0f);

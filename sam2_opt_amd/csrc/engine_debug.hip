@@ -152,14 +152,16 @@ extern "C" int sam2mi_debug_mlp(sam2mi_ctx* ctx, void* stream, const float* xn, 
   half_t* w1 = t.get<half_t>((size_t)H4 * C);
   half_t* w2 = t.get<half_t>((size_t)C * H4);
   half_t* h16 = fused ? nullptr : t.get<half_t>((size_t)M * H4);
+  half_t* wpk = fused ? t.get<half_t>(mlp_fused_pack_bytes(C) / 2) : nullptr;
   float* xs = iters > 0 ? t.get<float>((size_t)M * C) : nullptr;
-  if (!x16 || !w1 || !w2 || (!fused && !h16) || (iters > 0 && !xs)) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+  if (!x16 || !w1 || !w2 || (!fused && !h16) || (fused && !wpk) || (iters > 0 && !xs)) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
   CHK(cast_add_launch(xn, C, nullptr, 0, 0, 0.f, M, C, x16, C, nullptr, 0, s));
   CHK(cast_add_launch(W1, C, nullptr, 0, 0, 0.f, H4, C, w1, C, nullptr, 0, s));
   CHK(cast_add_launch(W2, H4, nullptr, 0, 0, 0.f, C, H4, w2, H4, nullptr, 0, s));
+  if (fused) CHK(mlp_fused_pack(w1, w2, C, wpk, s));
   auto run = [&](float* xio) -> int {
     if (fused) {
-      MlpFusedParams m{x16, C, w1, b1, w2, b2, xio, C, M};
+      MlpFusedParams m{x16, C, wpk, b1, b2, xio, C, M};
       CHK(mlp_fused_launch(m, C, s));
     } else {
       GemmParams p = gemm_params_zero();

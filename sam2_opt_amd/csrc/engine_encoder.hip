@@ -72,9 +72,9 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   if (b.q_pool) { H /= 2; W /= 2; wcur /= 2; }
   // 5-7. MLP
   CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s));
-  if (ctx->use_fused_mlp && mlp_fused_supported(Co)) {
+  if (ctx->use_fused_mlp && b.mlp_pack) {
     // stages 1-2: fc1 -> GELU -> fc2 -> +x in one kernel, the 4C-wide hidden never leaves the CU (mlp_fused.hip)
-    MlpFusedParams m{ctx->ws_a16, Co, b.fc1.w, b.fc1.b, b.fc2.w, b.fc2.b, x, Co, Mq};
+    MlpFusedParams m{ctx->ws_a16, Co, b.mlp_pack, b.fc1.b, b.fc2.b, x, Co, Mq};
     CHKI(run_mlp_fused(ctx, s, m, Co));
     return 0;
   }

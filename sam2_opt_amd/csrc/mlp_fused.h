@@ -4,13 +4,15 @@
 
 struct MlpFusedParams {
   const half_t* x16; int ldx;   // [M, C] f16 (LayerNorm output), ldx % 8 == 0
-  const half_t* w1;             // fc1 weight [4C, C] f16 (nn.Linear layout)
+  const half_t* wpack;          // fc1 + fc2 weights in the kernel's piece order (mlp_fused_pack)
   const float* b1;              // [4C]
-  const half_t* w2;             // fc2 weight [C, 4C] f16
   const float* b2;              // [C]
   float* x32; int ld32;         // residual stream [M, C] f32, updated in place; ld32 % 4 == 0
   int M;
 };
 bool mlp_fused_supported(int C);                     // C in {144, 288}
+// Re-orders fc1 [4C, C] and fc2 [C, 4C] (f16, nn.Linear layout) into the LDS-DMA piece stream of the kernel; once per block.
+size_t mlp_fused_pack_bytes(int C);
+hipError_t mlp_fused_pack(const half_t* w1, const half_t* w2, int C, half_t* wpack, hipStream_t s);
 hipError_t mlp_fused_launch(const MlpFusedParams& p, int C, hipStream_t s);
 hipError_t mlp_fused_init();                         // dynamic-LDS attributes, once

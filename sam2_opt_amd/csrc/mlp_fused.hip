@@ -22,6 +22,10 @@
 #include "mlp_fused.h"
 #include <cstdlib>
 
+#ifndef VSLICE
+#define VSLICE 10
+#endif
+
 namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -31,38 +35,60 @@ static __device__ __forceinline__ int pi23(int i) { return (i & ~12) | ((i & 4) 
 // Keeps a wave-uniform pointer in an SGPR pair and opaque to loop strength reduction, so that base + (32-bit lane offset)
 // selects the scalar-base form of global_load_lds (otherwise the loop carries one 64-bit VGPR address per piece).
 static __device__ __forceinline__ const char* sgpr_ptr(const char* p) {
-  unsigned long long v = reinterpret_cast<unsigned long long>(p);
-  asm volatile("" : "+s"(v));
-  return reinterpret_cast<const char*>(v);
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
 
 template <int N>
 static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int C, int TN, int G, int NST>
+template <int C, int TN, int NST>
 struct MlpCfg {
+  static constexpr int NW = 4;                      // one wave per SIMD
   static constexpr int KS = C / 16;                 // fc1 k-steps
   static constexpr int OT = (C + 31) / 32;          // output-channel tiles
   static constexpr int H4 = 4 * C;
-  static constexpr int NSTG = H4 / (32 * G);        // ring stages to stream (G chunks of 32 hidden units each)
-  static constexpr int W1P = G * KS, W2P = G * OT * 2, NP = W1P + W2P;
-  static constexpr int PW1 = (W1P + 3) / 4, PW2 = (W2P + 3) / 4, PPW = PW1 + PW2;   // pieces per wave per stage (uniform: counted vmcnt)
-  static constexpr int STAGE_B = (NP + (((W1P | W2P) & 3) ? 1 : 0)) * 1024;          // + one dump piece for the padding loads
+  static constexpr int NCH = H4 / 32;               // chunks of 32 hidden units = ring stages to stream
+  static constexpr int W1P = KS, W2P = OT * 2, NP = W1P + W2P;
+  static constexpr int PPW = (NP + NW - 1) / NW;    // pieces per wave per stage (uniform: counted vmcnt)
+  static constexpr int NPP = PPW * NW;              // pieces per chunk in the packed weight image (zero pieces pad NP up to a multiple of 4)
+  static constexpr int STAGE_B = NPP * 1024;
   static constexpr int LDS_B = NST * STAGE_B + H4 * 4;
-  static_assert(C % 16 == 0 && H4 % (32 * G) == 0, "shape");
+  static_assert(C % 16 == 0 && NST >= 3, "shape");
   static_assert((NST - 1) * PPW <= 63, "vmcnt range");
 };
 
-template <int C, int TN, int G, int NST, int FB>
+// erf-GELU without the |x| clamp of gelu_erf_fast (common.h): for finite x the exponential underflows long before
+// |x| * q can overflow, and the operands here are finite (LayerNorm output times weights).  relu(x) = med3(x, 0, inf):
+// fmaxf would cost a second v_max for sNaN quieting.  Written per element; the compiler packs pairs into v_pk_* ops.
+static __device__ __forceinline__ float gelu_nc(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.23164189f, 1.0f));
+  const float m = x * 0.84932180f;
+  const float e = __builtin_amdgcn_exp2f(-(m * m));
+  float poly = fmaf(0.5307027145f, t, -0.7265760135f);
+  poly = fmaf(poly, t, 0.7107068705f);
+  poly = fmaf(poly, t, -0.142248368f);
+  poly = fmaf(poly, t, 0.127414796f);
+  return fmaf(-ax, poly * t * e, __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()));
+}
+
+// Software pipeline over the 4C / 32 hidden chunks (one wave per SIMD, the flash256_v3 scheme):
+//   iteration j:   S_{j+1} = W1_{j+1} X^T  [MFMA]   beside   P_j = GELU(S_j + b1_j)  [VALU]   beside the LDS-DMA of chunk j+3
+//                  Y^T += W2_j P_j          [MFMA]
+// All fragments of both products are read from LDS at the top of the iteration (one wave per SIMD has the registers), the
+// first phase is laid out with sched_group_barrier as (1 MFMA, 1 DMA piece, a slice of the VALU work) groups.
+template <int C, int TN, int NST>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpFusedParams p) {
-  using K = MlpCfg<C, TN, G, NST>;
-  constexpr int KS = K::KS, OT = K::OT, H4 = K::H4, NSTG = K::NSTG, W1P = K::W1P, W2P = K::W2P, NP = K::NP, PW1 = K::PW1, PW2 = K::PW2, PPW = K::PPW, STAGE_B = K::STAGE_B;
+  using K = MlpCfg<C, TN, NST>;
+  constexpr int NW = K::NW, KS = K::KS, OT = K::OT, H4 = K::H4, NCH = K::NCH, W1P = K::W1P, NP = K::NP, PPW = K::PPW, STAGE_B = K::STAGE_B;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* bias_lds = reinterpret_cast<float*>(smem + NST * STAGE_B);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, fh = lane >> 5;
-  const int tok0 = (blockIdx.x * 4 + wave) * (32 * TN);
+  const int tok0 = (blockIdx.x * NW + wave) * (32 * TN);
 
   // X fragments (B operand): X[token fr][16 s + 8 fh + j]; rows past M are clamped (their results are not stored)
   half8 xf[TN][KS];
@@ -75,42 +101,56 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpFusedParams 
   for (int i = tid; i < H4; i += 256) bias_lds[i] = p.b1[i];
   __syncthreads();                           // bias table visible (also retires the X loads)
 
-  // ---- LDS-DMA: piece q of a stage = fragment tile (32 rows x 32 B); lane l carries row l >> 1, 16-B half (l & 1) ^ swz(row)
-  const int prow = lane >> 1, phalf = (lane & 1) ^ ((prow >> 3) & 1);
-  const unsigned off_w1 = (unsigned)(prow * C + 8 * phalf) * 2u;                               // bytes
-  const unsigned off_w2 = (unsigned)(prow * H4 + 8 * phalf) * 2u;
-  const unsigned off_w2_last = (unsigned)((min(32 * (OT - 1) + prow, C - 1) - 32 * (OT - 1)) * H4 + 8 * phalf) * 2u;
-  const char* w1b = reinterpret_cast<const char*>(p.w1);
-  const char* w2b = reinterpret_cast<const char*>(p.w2);
-  // Step i of a stage is the same KIND of piece on all four waves (W1 pieces first, each kind padded to a multiple of 4 with
-  // dumped re-loads of its first piece), so the operand base is a compile-time choice and only scalar coordinates vary.
-  auto issue = [&](int st) {                 // stage st -> ring slot st % NST
-    char* sb = smem + (st % NST) * STAGE_B;
-    const int hid0 = st * (32 * G);
+  // ---- LDS-DMA from the PACKED weight image (mlp_fused_pack): chunk j = NPP consecutive 1-KiB pieces, each one fragment
+  // tile (32 rows x 32 B, halves swapped on rows with bit 3 set) exactly as it sits in LDS.  Every piece is 8 full cache
+  // lines (strided 32-B row segments of the nn.Linear layout would cost 32 L2 requests per KiB: measured 7.5 B/clk/CU).
+  // Ring step i loads chunk min(i, NCH-1) into slot i % NST: past the end the last chunk is loaded again into a free slot
+  // (read only by the discarded S chain of the final iteration), so every iteration issues exactly PPW pieces per wave.
+  const char* wp = reinterpret_cast<const char*>(p.wpack);
+  const unsigned lane_off = (unsigned)lane * 16u;
+  auto issue = [&](int i) {
+    char* sb = smem + (i % NST) * STAGE_B;
+    const char* cb = wp + (size_t)min(i, NCH - 1) * STAGE_B;
 #pragma unroll
-    for (int i = 0; i < PW1; ++i) {
-      const int q = wave + 4 * i;            // wave-uniform
-      const bool pad = (W1P & 3) != 0 && q >= W1P;
-      const int qe = pad ? 0 : q;
-      const int g = qe / KS, ks = qe - g * KS;
-      const char* src = sgpr_ptr(w1b + ((size_t)(hid0 + 32 * g) * C + 16 * ks) * 2);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + off_w1), (lds_ptr_t)(sb + (pad ? NP : q) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < PW2; ++i) {
-      const int q = wave + 4 * i;
-      const bool pad = (W2P & 3) != 0 && q >= W2P;
-      const int qe = pad ? 0 : q;
-      const int g = qe / (2 * OT), r = qe - g * (2 * OT), t = r >> 1, ks = r & 1;
-      const char* src = sgpr_ptr(w2b + ((size_t)(32 * t) * H4 + hid0 + 32 * g + 16 * ks) * 2);
-      const unsigned off = (C % 32 != 0 && t == OT - 1) ? off_w2_last : off_w2;
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + off), (lds_ptr_t)(sb + (pad ? NP : W1P + q) * 1024), 16, 0, 0);
+    for (int k = 0; k < PPW; ++k) {
+      const int q = wave + NW * k;           // wave-uniform
+      const char* src = sgpr_ptr(cb + q * 1024);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + lane_off), (lds_ptr_t)(sb + q * 1024), 16, 0, 0);
     }
   };
   // fragment read addresses (bytes inside a piece)
   const int r1 = pi23(fr);
   const int rd_w1 = r1 * 32 + ((fh ^ ((r1 >> 3) & 1)) << 4);
-  const int rd_w2 = fr * 32 + ((fh ^ ((fr >> 3) & 1)) << 4);
+  const int rd_w2 = W1P * 1024 + fr * 32 + ((fh ^ ((fr >> 3) & 1)) << 4);
+  struct W1F { half8 f[KS]; };
+  struct W2F { half8 f[2 * OT]; };
+  auto read_w1 = [&](int i) {
+    const char* sb = smem + (i % NST) * STAGE_B + rd_w1;
+    W1F w;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) w.f[s] = *reinterpret_cast<const half8*>(sb + s * 1024);
+    return w;
+  };
+  auto read_w2 = [&](int i) {
+    const char* sb = smem + (i % NST) * STAGE_B + rd_w2;
+    W2F w;
+#pragma unroll
+    for (int f = 0; f < 2 * OT; ++f) w.f[f] = *reinterpret_cast<const half8*>(sb + f * 1024);
+    return w;
+  };
+  auto chain = [&](const W1F& w, f32x16 (&sa)[TN]) {           // S^T = W1_chunk X^T (first MFMA starts from the constant 0)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      f32x16 z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+      sa[tn] = mfma32(w.f[0], xf[tn][0], z);
+    }
+#pragma unroll
+    for (int s = 1; s < KS; ++s)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) sa[tn] = mfma32(w.f[s], xf[tn][s], sa[tn]);
+  };
 
   f32x16 acc[TN][OT];
 #pragma unroll
@@ -121,93 +161,55 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpFusedParams 
       for (int r = 0; r < 16; ++r) acc[tn][t][r] = 0.f;
 
 #pragma unroll
-  for (int st = 0; st < NST - 1; ++st)
-    if (st < NSTG) issue(st);
+  for (int i = 0; i < NST - 1; ++i) issue(i);
+  wait_vm<(NST - 2) * PPW>();
+  __builtin_amdgcn_s_barrier();
+  f32x16 scur[TN];
+  {
+    const W1F w = read_w1(0);
+    __builtin_amdgcn_sched_barrier(0);
+    chain(w, scur);
+  }
 
 #pragma nounroll
-  for (int st = 0; st < NSTG; ++st) {
-    // stage st landed (the NST-2 younger stages may stay in flight), everyone is done with the slot refilled next
+  for (int j = 0; j < NCH; ++j) {
+    // chunk j+1 landed (NST-3 younger ones may stay in flight); every wave is past chunk j-1 -> slot (j-1) % NST is free
+    wait_vm<(NST - 3) * PPW>();
+    __builtin_amdgcn_s_barrier();
+    const W1F w1 = read_w1(j + 1);
+    const W2F w2 = read_w2(j);
+    // b1 of this chunk: accumulator register 8 ks + e <-> hidden unit 32 j + 16 ks + 8 fh + e
+    f32x4 bv[4];
     {
-      const int later = min(NST - 2, NSTG - 1 - st);
-      if (NST >= 4 && later == 2) wait_vm<2 * PPW>();
-      else if (NST >= 3 && later == 1) wait_vm<PPW>();
-      else wait_vm<0>();
-      __builtin_amdgcn_s_barrier();
-      if (st + NST - 1 < NSTG) issue(st + NST - 1);
+      const float* bl = bias_lds + 32 * j + 8 * fh;
+      bv[0] = *reinterpret_cast<const f32x4*>(bl); bv[1] = *reinterpret_cast<const f32x4*>(bl + 4);
+      bv[2] = *reinterpret_cast<const f32x4*>(bl + 16); bv[3] = *reinterpret_cast<const f32x4*>(bl + 20);
     }
-    const char* sb = smem + (st % NST) * STAGE_B;
-    const char* sW1 = sb + rd_w1;
-    const char* sW2 = sb + W1P * 1024 + rd_w2;
+    __builtin_amdgcn_sched_barrier(0);
+    issue(j + NST - 1);
+    f32x16 snext[TN];
+    chain(w1, snext);
+    half8 pf[TN][2];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      // ---- S^T = W1_chunk X^T + b1   (bias = initial accumulator; registers 8 ks + j <-> hidden 16 ks + 8 fh + j)
-      f32x16 sacc[TN];
-      {
-        const float* bl = bias_lds + st * (32 * G) + 32 * g + 8 * fh;
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl), b1 = *reinterpret_cast<const f32x4*>(bl + 4);
-        const f32x4 b2 = *reinterpret_cast<const f32x4*>(bl + 16), b3 = *reinterpret_cast<const f32x4*>(bl + 20);
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+      for (int r = 0; r < 16; ++r) pf[tn][r >> 3][r & 7] = (half_t)gelu_nc(scur[tn][r] + bv[r >> 2][r & 3]);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { sacc[tn][j] = b0[j]; sacc[tn][4 + j] = b1[j]; sacc[tn][8 + j] = b2[j]; sacc[tn][12 + j] = b3[j]; }
-      }
-      {
-        constexpr int NB = (KS + FB - 1) / FB;
-        half8 cur[FB], nxt[FB];
-#pragma unroll
-        for (int j = 0; j < FB; ++j)
-          if (j < KS) cur[j] = *reinterpret_cast<const half8*>(sW1 + (g * KS + j) * 1024);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-#pragma unroll
-          for (int j = 0; j < FB; ++j)
-            if ((b + 1) * FB + j < KS) nxt[j] = *reinterpret_cast<const half8*>(sW1 + (g * KS + (b + 1) * FB + j) * 1024);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < FB; ++j)
-            if (b * FB + j < KS) {
-#pragma unroll
-              for (int tn = 0; tn < TN; ++tn) sacc[tn] = mfma32(cur[j], xf[tn][b * FB + j], sacc[tn]);
-            }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < FB; ++j) cur[j] = nxt[j];
-        }
-      }
-      // ---- P = GELU(S^T) as f16 B operands
-      half8 pf[TN][2];
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pf[tn][r >> 3][r & 7] = (half_t)gelu_erf_fast(sacc[tn][r]);
-      // ---- Y^T += W2_chunk P
-      {
-        constexpr int NF = 2 * OT, NB = (NF + FB - 1) / FB;
-        const char* sW2g = sW2 + g * (2 * OT) * 1024;
-        half8 cur[FB], nxt[FB];
-#pragma unroll
-        for (int j = 0; j < FB; ++j)
-          if (j < NF) cur[j] = *reinterpret_cast<const half8*>(sW2g + j * 1024);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-#pragma unroll
-          for (int j = 0; j < FB; ++j)
-            if ((b + 1) * FB + j < NF) nxt[j] = *reinterpret_cast<const half8*>(sW2g + ((b + 1) * FB + j) * 1024);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < FB; ++j)
-            if (b * FB + j < NF) {
-              const int f = b * FB + j;
-#pragma unroll
-              for (int tn = 0; tn < TN; ++tn) acc[tn][f >> 1] = mfma32(cur[j], pf[tn][f & 1], acc[tn][f >> 1]);
-            }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < FB; ++j) cur[j] = nxt[j];
-        }
-      }
+    for (int g = 0; g < KS * TN; ++g) {                  // phase schedule: 1 MFMA, 1 LDS-DMA piece (while there are any), VALU slice
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (g < PPW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, VSLICE, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- Y^T += W2_chunk P
+#pragma unroll
+    for (int f = 0; f < 2 * OT; ++f)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tn][f >> 1] = mfma32(w2.f[f], pf[tn][f & 1], acc[tn][f >> 1]);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) scur[tn] = snext[tn];
   }
+  wait_vm<0>();                                          // the trailing (duplicate) DMA pieces must land before the LDS is released
 
   // ---- x += Y + b2   (accumulator row = channel 32 t + 8 g + 4 fh + 0..3, column = token fr)
 #pragma unroll
@@ -233,27 +235,46 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpFusedParams 
   }
 }
 
-template <int C, int TN, int G, int NST, int FB>
+// one thread per 16-B unit of the packed image
+template <int C, int TN, int NST>
+__global__ void mlp_pack_kernel(const half_t* __restrict__ w1, const half_t* __restrict__ w2, half_t* __restrict__ out) {
+  using K = MlpCfg<C, TN, NST>;
+  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= (long)K::NCH * K::NPP * 64) return;
+  const int j = (int)(u / (K::NPP * 64)), rem = (int)(u % (K::NPP * 64));
+  const int q = rem >> 6, l = rem & 63, row = l >> 1, h = (l & 1) ^ ((row >> 3) & 1);
+  half8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (half_t)0.f;
+  if (q < K::W1P) v = *reinterpret_cast<const half8*>(w1 + (size_t)(32 * j + row) * C + 16 * q + 8 * h);
+  else if (q < K::NP) {
+    const int r = q - K::W1P, t = r >> 1, ks = r & 1, c = 32 * t + row;
+    if (c < C) v = *reinterpret_cast<const half8*>(w2 + (size_t)c * K::H4 + 32 * j + 16 * ks + 8 * h);
+  }
+  *reinterpret_cast<half8*>(out + (size_t)u * 8) = v;
+}
+
+template <int C, int TN, int NST>
 hipError_t launch_cfg(const MlpFusedParams& p, hipStream_t s) {
-  using K = MlpCfg<C, TN, G, NST>;
-  const int wg_tok = 128 * TN;
+  using K = MlpCfg<C, TN, NST>;
+  const int wg_tok = 32 * TN * K::NW;
   const int grid = (p.M + wg_tok - 1) / wg_tok;
-  mlp_fused_kernel<C, TN, G, NST, FB><<<dim3(grid), dim3(256), K::LDS_B, s>>>(p);
+  mlp_fused_kernel<C, TN, NST><<<dim3(grid), dim3(64 * K::NW), K::LDS_B, s>>>(p);
   return hipGetLastError();
 }
-template <int C, int TN, int G, int NST, int FB>
+template <int C, int TN, int NST>
 hipError_t attr_cfg() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, TN, G, NST, FB>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, MlpCfg<C, TN, G, NST>::LDS_B);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, TN, NST>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, MlpCfg<C, TN, NST>::LDS_B);
 }
 }  // namespace
 
-// Configurations: C = 144: 64 tokens per wave, 2 chunks per stage (38 + 2 padding pieces), 3-stage ring (117 KiB);
-// C = 288: 32 tokens per wave, 1 chunk per stage (36 + 4 padding pieces), 4-stage ring (148 KiB).
+// Configurations: C = 144: 64 tokens per wave (256 per workgroup), 19 + 1 padding pieces per chunk, 4-slot ring (82 KiB);
+// C = 288: 32 tokens per wave (128 per workgroup), 36 pieces per chunk, 4-slot ring (149 KiB).
 // C = 576 does not fit: 32 tokens need 144 (X) + 288 (Y^T) of the 512 registers and the compiler spills X into scratch
 // (reloaded inside the MFMA chains behind vmcnt(0), which also drains the DMA ring) - stage 3 stays on the two-GEMM path.
 hipError_t mlp_fused_init() {
-  hipError_t e[2] = {attr_cfg<144, 2, 2, 3, 5>(), attr_cfg<288, 1, 1, 4, 6>()};
+  hipError_t e[2] = {attr_cfg<144, 2, 4>(), attr_cfg<288, 1, 4>()};
   for (int i = 0; i < 2; ++i)
     if (e[i] != hipSuccess) return e[i];
   return hipSuccess;
@@ -261,12 +282,27 @@ hipError_t mlp_fused_init() {
 
 bool mlp_fused_supported(int C) { return C == 144 || C == 288; }
 
+size_t mlp_fused_pack_bytes(int C) {
+  if (C == 144) return (size_t)MlpCfg<144, 2, 4>::NCH * MlpCfg<144, 2, 4>::STAGE_B;
+  if (C == 288) return (size_t)MlpCfg<288, 1, 4>::NCH * MlpCfg<288, 1, 4>::STAGE_B;
+  return 0;
+}
+
+hipError_t mlp_fused_pack(const half_t* w1, const half_t* w2, int C, half_t* wpack, hipStream_t s) {
+  const long units = (long)(mlp_fused_pack_bytes(C) / 16);
+  if (units == 0) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((units + 255) / 256)), block(256);
+  if (C == 144) mlp_pack_kernel<144, 2, 4><<<grid, block, 0, s>>>(w1, w2, wpack);
+  else mlp_pack_kernel<288, 1, 4><<<grid, block, 0, s>>>(w1, w2, wpack);
+  return hipGetLastError();
+}
+
 hipError_t mlp_fused_launch(const MlpFusedParams& p, int C, hipStream_t s) {
   if (p.M <= 0) return hipSuccess;
   if ((p.ldx & 7) || (p.ld32 & 3)) return hipErrorInvalidValue;
   switch (C) {
-    case 144: return launch_cfg<144, 2, 2, 3, 5>(p, s);
-    case 288: return launch_cfg<288, 1, 1, 4, 6>(p, s);
+    case 144: return launch_cfg<144, 2, 4>(p, s);
+    case 288: return launch_cfg<288, 1, 4>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
