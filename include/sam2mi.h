@@ -194,6 +194,8 @@ int sam2mi_profile_read(sam2mi_ctx* ctx, double* gemm_ms, double* gemm_flops, in
 
 /* Same for the fused Hiera MLP kernel (mlp_fused_kernel: fc1 + GELU + fc2 + residual; flops = 2 * 2 * M * C * 4C per launch). */
 int sam2mi_profile_read_mlp(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* launches);
+/* Same for the X-stationary short-K GEMM (gemm_xs_kernel: QKV / projection / fc1 of Hiera stages 1-3; flops = 2 M N K). */
+int sam2mi_profile_read_xs(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* launches);
 
 /* Debug/test entry points: single kernels behind the C ABI (used by tests/test_kernels_gpu.py). */
 int sam2mi_debug_gemm(sam2mi_ctx* ctx, void* stream, const float* A, const float* W, const float* bias, int M, int N, int K,

@@ -63,7 +63,22 @@ static void prof_end(ProfAcc& a, hipStream_t s, hipEvent_t e0, hipEvent_t e1, do
   a.launches += 1;
 }
 
+// X-stationary kernel for the encoder's short-K linears when the operands allow it
+static bool xs_eligible(const sam2mi_ctx* ctx, const GemmParams& p) {
+  return ctx->use_xs && p.xs_pack && p.tile_hint == 0 && p.M >= 16384 && p.lda == p.K && gemm_xs_supported(p.N, p.K) &&
+         (p.act == ACT_NONE || p.act == ACT_GELU) && p.rope_cols == 0 && p.res_mod == 0 && !p.outT32 && (p.n_split >= p.N || (p.n_split & 31) == 0) &&
+         !(p.out32 && p.out16) && (p.out32 || p.out16) && (!p.res || p.out32) && p.bias && (!p.col_scale || p.xs_scale_cols > 0);
+}
 int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p) {
+  if (xs_eligible(ctx, p)) {
+    GemmXsParams x{p.A, p.lda, p.xs_pack, p.bias, p.col_scale, p.xs_scale_cols, p.act, p.M, p.N, p.n_split, p.out16, p.ld16, p.outT16, p.ldT16,
+                   p.out32, p.ld32, p.res, p.ldres, 0};
+    hipEvent_t e0, e1;
+    if (ctx->prof_on) prof_begin(ctx, ctx->prof_xs, s, e0, e1);
+    CHK(gemm_xs_launch(x, p.K, s));
+    if (ctx->prof_on) prof_end(ctx->prof_xs, s, e0, e1, 2.0 * p.M * (double)p.N * p.K);
+    return 0;
+  }
   hipEvent_t e0, e1;
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_gemm, s, e0, e1);
   CHK(gemm_launch(p, s));
@@ -96,7 +111,7 @@ int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p) {
 
 GemmParams lin_params(const half_t* A, int lda, int M, const Lin16& L) {
   GemmParams p = gemm_params_zero();
-  p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.K; p.M = M; p.N = L.N; p.K = L.K; p.bias = L.b; p.n_split = L.N;
+  p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.K; p.M = M; p.N = L.N; p.K = L.K; p.bias = L.b; p.n_split = L.N; p.xs_pack = L.xs_pack;
   return p;
 }
 
@@ -246,9 +261,11 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   if (ctx->cfg.bank_slots <= 0) ctx->cfg.bank_slots = 64;
   if (ctx->cfg.feat_slots <= 0) ctx->cfg.feat_slots = 16;
   ctx->use_fused_mlp = getenv("SAM2MI_NO_FUSED_MLP") == nullptr;
+  ctx->use_xs = getenv("SAM2MI_NO_XS") == nullptr;
   hipError_t e = gemm_init();
   if (e == hipSuccess) e = flash256_init();
   if (e == hipSuccess) e = mlp_fused_init();
+  if (e == hipSuccess) e = gemm_xs_init();
   if (e != hipSuccess) {
     sam2mi_set_error(nullptr, "gemm_init", hipGetErrorString(e));
     delete ctx;
@@ -262,7 +279,7 @@ extern "C" void sam2mi_destroy(sam2mi_ctx* ctx) {
   if (!ctx) return;
   hipDeviceSynchronize();
   for (void* p : ctx->allocs) hipFree(p);
-  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp}) {
+  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp, &ctx->prof_xs}) {
     for (auto& pr : a->pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto& pr : a->pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   }
@@ -288,14 +305,14 @@ extern "C" int sam2mi_load_weight(sam2mi_ctx* ctx, const char* key, const float*
 extern "C" int sam2mi_profile_enable(sam2mi_ctx* ctx, int on) {
   ctx->prof_on = on != 0;
   if (on) {
-    for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp}) { a->ms = 0; a->flops = 0; a->launches = 0; }
+    for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp, &ctx->prof_xs}) { a->ms = 0; a->flops = 0; a->launches = 0; }
   }
   return 0;
 }
 
 extern "C" int sam2mi_profile_read(sam2mi_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches,
                                    double* attn_ms, double* attn_flops, int64_t* attn_launches) {
-  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp}) {
+  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp, &ctx->prof_xs}) {
     for (auto& pr : a->pending) {
       hipEventSynchronize(pr.second);
       float ms = 0;
@@ -314,9 +331,14 @@ extern "C" int sam2mi_profile_read(sam2mi_ctx* ctx, double* gemm_ms, double* gem
   return 0;
 }
 
+static int prof_read_one(ProfAcc& a, double* ms, double* flops, int64_t* launches);
+extern "C" int sam2mi_profile_read_xs(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* launches) {
+  return ctx ? prof_read_one(ctx->prof_xs, ms, flops, launches) : 1;
+}
 extern "C" int sam2mi_profile_read_mlp(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* launches) {
-  if (!ctx) return 1;
-  ProfAcc& a = ctx->prof_mlp;
+  return ctx ? prof_read_one(ctx->prof_mlp, ms, flops, launches) : 1;
+}
+static int prof_read_one(ProfAcc& a, double* ms, double* flops, int64_t* launches) {
   for (auto& pr : a.pending) {
     hipEventSynchronize(pr.second);
     float t = 0;
@@ -377,6 +399,11 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
       b.proj = pk.lin16(p + "attn.proj");
       b.fc1 = pk.lin16(p + "mlp.layers.0");
       b.fc2 = pk.lin16(p + "mlp.layers.1");
+      for (Lin16* L : {&b.qkv, &b.proj, &b.fc1}) {       // stages 1-3: short-K linears also in the X-stationary kernel's piece order
+        if (!pk.ok || !L->w || !gemm_xs_supported(L->N, L->K) || (L == &b.fc1 && mlp_fused_supported(b.dim_out))) continue;
+        L->xs_pack = (half_t*)dalloc(ctx, gemm_xs_pack_bytes(L->N, L->K));
+        if (!L->xs_pack || gemm_xs_pack(L->w, L->N, L->K, L->K, L->xs_pack, nullptr) != hipSuccess) pk.ok = false;
+      }
       if (pk.ok && mlp_fused_supported(b.dim_out)) {     // stages 1-2: weights also in the fused MLP kernel's piece order
         b.mlp_pack = (half_t*)dalloc(ctx, mlp_fused_pack_bytes(b.dim_out));
         if (!b.mlp_pack || mlp_fused_pack(b.fc1.w, b.fc2.w, b.dim_out, b.mlp_pack, nullptr) != hipSuccess) pk.ok = false;

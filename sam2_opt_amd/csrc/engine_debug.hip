@@ -40,6 +40,16 @@ extern "C" int sam2mi_debug_gemm(sam2mi_ctx* ctx, void* stream, const float* A, 
   p.A = a16; p.lda = K; p.W = w16; p.ldw = K; p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act & 0xFF; p.n_split = N;
   p.tile_hint = act >> 8;            // tests: force a tile / kernel variant
   p.res = residual; p.ldres = N; p.out32 = out; p.ld32 = N;
+  if (p.tile_hint == 30) {               // X-stationary kernel (K = 144 / 288 / 576): pack W, then the production dispatch path
+    if (!gemm_xs_supported(N, K)) return sam2mi_set_error(ctx, __func__, "gemm_xs needs K in {144,288,576}, N % 8 == 0");
+    half_t* wp = t.get<half_t>(gemm_xs_pack_bytes(N, K) / 2);
+    if (!wp) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+    CHK(gemm_xs_pack(w16, N, K, K, wp, s));
+    GemmXsParams x{a16, K, wp, bias, nullptr, 0, p.act, M, N, N, nullptr, 0, nullptr, 0, out, N, residual, N, 0};
+    CHK(gemm_xs_launch(x, K, s));
+    CHK(hipStreamSynchronize(s));
+    return 0;
+  }
   CHKI(run_gemm(ctx, s, p));
   CHK(hipStreamSynchronize(s));
   return 0;
@@ -224,12 +234,24 @@ extern "C" int sam2mi_debug_gemm_bench(sam2mi_ctx* ctx, void* stream, int M, int
   else if (mode == 1) { p.out32 = o32; p.ld32 = N; p.res = o32; p.ldres = N; }   // f32 in-place residual (proj / fc2 style)
   else if (mode == 3) { p.out16 = o16; p.ld16 = N; p.act = ACT_GELU; }          // f16 output through GELU (fc1 style)
   // mode 2: no output at all (main-loop-only timing, tuning aid)
-  for (int i = 0; i < 3; ++i) CHK(gemm_launch(p, s));
+  half_t* wpk = nullptr;
+  GemmXsParams xsp{};
+  if (tile_hint == 30) {
+    if (!gemm_xs_supported(N, K)) return sam2mi_set_error(ctx, __func__, "gemm_xs needs K in {144,288,576}, N % 8 == 0");
+    wpk = t.get<half_t>(gemm_xs_pack_bytes(N, K) / 2);
+    float* bz = t.get<float>((size_t)N);
+    if (!wpk || !bz) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+    CHK(hipMemsetAsync(bz, 0, (size_t)N * sizeof(float), s));
+    CHK(gemm_xs_pack(w16, N, K, K, wpk, s));
+    xsp = GemmXsParams{a16, K, wpk, bz, nullptr, 0, p.act, M, N, N, p.out16, p.ld16, nullptr, 0, p.out32, p.ld32, p.res, p.ldres, 0};
+  }
+  auto launch = [&]() -> hipError_t { return tile_hint == 30 ? gemm_xs_launch(xsp, K, s) : gemm_launch(p, s); };
+  for (int i = 0; i < 3; ++i) CHK(launch());
   hipEvent_t e0, e1;
   CHK(hipEventCreate(&e0));
   CHK(hipEventCreate(&e1));
   CHK(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i) CHK(gemm_launch(p, s));
+  for (int i = 0; i < iters; ++i) CHK(launch());
   CHK(hipEventRecord(e1, s));
   CHK(hipEventSynchronize(e1));
   float ms = 0;

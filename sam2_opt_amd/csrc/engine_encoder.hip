@@ -33,6 +33,7 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
     GemmParams p = lin_params(ctx->ws_a16, C, M, b.qkv);
     p.n_split = 2 * Co;
     p.col_scale = b.qscale;                 // q pre-scaled (f32, before the f16 rounding) for the exp2-domain softmax
+    p.xs_scale_cols = Co;                   // k / v columns have scale 1
     p.out16 = ctx->ws_qk16; p.ld16 = 2 * Co;
     p.outT16 = ctx->ws_vT16; p.ldT16 = M;
     CHKI(run_gemm(ctx, s, p));

@@ -25,6 +25,8 @@ struct GemmParams {
   const float* rope_cos; const float* rope_sin;  // [rope_len, rope_dim/2]
   int rope_len, rope_rows, rope_cols, rope_dim;
   int tile_hint;                 // 0 = automatic tile choice; 1..5 force a v2 tile (benchmarks)
+  const half_t* xs_pack;         // W in the piece order of the X-stationary kernel (gemm_xs.hip), or null
+  int xs_scale_cols;             // col_scale is 1 from this column on (lets the X-stationary kernel keep only the q scale); 0: unknown
 };
 
 static inline GemmParams gemm_params_zero() {

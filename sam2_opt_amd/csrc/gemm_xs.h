@@ -1,0 +1,25 @@
+// X-stationary GEMM for K = 144 / 288 / 576 (gemm_xs.hip): X rows live in registers, the packed weight streams through LDS.
+#pragma once
+#include <algorithm>
+#include "gemm.h"
+
+struct GemmXsParams {
+  const half_t* x16; int ldx;      // [M, K] f16 activations (K-contiguous), ldx % 8 == 0
+  const half_t* wpack;             // weight [N, K] in piece order (gemm_xs_pack)
+  const float* bias;               // [N]
+  const float* col_scale;          // [>= scale_cols] or null: v *= col_scale[n] after bias / activation, columns n < scale_cols
+  int scale_cols;                  //   (the q pre-scale of a QKV projection); % 32 == 0, <= 576, <= n_split
+  int act;                         // ACT_NONE or ACT_GELU (row-major columns only)
+  int M, N;                        // N % 8 == 0
+  int n_split;                     // columns >= n_split go to outT16 (multiple of 32; == N: none)
+  half_t* out16; int ld16;         // f16 row-major output of columns < n_split (or null), ld16 % 8 == 0
+  half_t* outT16; int ldT16;       // outT16[(n - n_split) * ldT16 + m], ldT16 % 4 == 0
+  float* out32; int ld32;          // f32 row-major output of columns < n_split (or null)
+  const float* res; int ldres;     // f32 residual added to out32 (may alias out32)
+  int splits;                      // 0: automatic column split
+};
+bool gemm_xs_supported(int N, int K);
+size_t gemm_xs_pack_bytes(int N, int K);
+hipError_t gemm_xs_pack(const half_t* w, int N, int K, int ldw, half_t* wpack, hipStream_t s);
+hipError_t gemm_xs_launch(const GemmXsParams& p, int K, hipStream_t s);
+hipError_t gemm_xs_init();

@@ -1,0 +1,286 @@
+// X-stationary GEMM for short K (K = 144 / 288 / 576: the QKV, output-projection and fc1 linears of Hiera stages 1-3,
+// /root/reference/sam2/sam2/modeling/backbones/hieradet.py:56-81 and :123-129):   out = epi( X[M,K] . W[N,K]^T ).
+//
+// Why a second GEMM kernel: in the tiled kernel (gemm2.hip) every 128x128 output tile re-fetches its A and W panels from
+// L2 into LDS, and with K <= 576 a workgroup lives for 3-9 K tiles - the kernel is bound by the per-CU L2->LDS path and by
+// prologue/epilogue that nothing overlaps.  Here the short K is used the other way round:
+//   * a wave keeps its 32 token rows of X (all of K) in REGISTERS as MFMA operands for its whole life (K/16 fragments),
+//     so X is read from HBM/L2 exactly once and never touches LDS;
+//   * the weight matrix streams past in 36-KiB stages (576 / K chunks of 32 output columns) through a 2-slot LDS ring
+//     by LDS-DMA, from an image packed at weight-load time so that every 1-KiB piece is one MFMA fragment tile
+//     (32 rows x 32 B, 8 full cache lines per piece, halves swapped on rows with bit 3 set: conflict-free ds_read_b128);
+//   * per chunk one accumulator tile: S^T = W_chunk . X^T (row-major outputs: W rows permuted by pi23 so that a lane
+//     owns 8 consecutive output columns of its token -> 16-B f16 / 32-B f32 stores straight from the accumulator) or
+//     S = X . W_chunk^T (transposed output V^T: a lane owns 4 consecutive tokens of its column -> 8-B stores);
+//   * the epilogue (bias, erf-GELU, column scale, f32 residual) runs on that one tile while the other wave of the SIMD is in
+//     its MFMA chain (two workgroups of 4 waves per CU).
+// Grid = (M / 128 token blocks) x (column splits): the column range is split so that the chip holds two waves per SIMD.
+#include "gemm_xs.h"
+
+namespace {
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+static __device__ __forceinline__ int pi23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+static __device__ __forceinline__ const char* sgpr_ptr(const char* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
+constexpr int NW = 4;                    // waves per workgroup (two workgroups per CU)
+constexpr int STAGE_PIECES = 36;         // 1-KiB pieces per ring stage (9 per wave)
+constexpr int STAGE_B = STAGE_PIECES * 1024;
+constexpr int NST = 2;
+constexpr int MAX_COLS = 1152;           // output columns per workgroup (bias table in LDS)
+constexpr int MAX_SCALE = 576;           // of which at most this many leading ones carry a column scale
+constexpr int LDS_B = NST * STAGE_B + (MAX_COLS + MAX_SCALE) * 4;       // 80,640 B: two workgroups per CU
+template <int K> constexpr int frag_batch() { return K == 576 ? 4 : (K == 288 ? 6 : 5); }   // fragments per LDS read batch (double-buffered)
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmXsParams p) {
+  constexpr int KS = K / 16;             // k-steps = pieces per chunk
+  constexpr int CPS = STAGE_PIECES / KS; // chunks (of 32 output columns) per stage
+  constexpr int FB = frag_batch<K>();
+  static_assert(KS * CPS == STAGE_PIECES, "K must divide 576");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int tok0 = (blockIdx.x * NW + wave) * 32;
+  // this workgroup's stage range (column split)
+  const int nstages = (p.N + 32 * CPS - 1) / (32 * CPS);
+  const int per = (nstages + gridDim.y - 1) / gridDim.y;
+  const int st_lo = blockIdx.y * per, st_hi = min(nstages, st_lo + per);
+  if (st_lo >= st_hi) return;
+
+  // X fragments: X[token fr][16 s + 8 fh + e]; rows past M are clamped (never stored)
+  half8 xf[KS];
+  {
+    const half_t* xp = p.x16 + (size_t)min(tok0 + fr, p.M - 1) * p.ldx + fh * 8;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xf[s] = *reinterpret_cast<const half8*>(xp + s * 16);
+  }
+  // bias (and the column scale of the first scale_cols columns) of this workgroup's column range, in LDS: a global load
+  // at the top of every chunk sits in front of the MFMA chain it initialises (measured: ~1 us per chunk under load)
+  float* bias_lds = reinterpret_cast<float*>(smem + NST * STAGE_B);
+  float* scale_lds = bias_lds + MAX_COLS;
+  const int col_lo = st_lo * CPS * 32, col_hi = min(p.N, st_hi * CPS * 32);
+  for (int i = tid; i < MAX_COLS; i += 256) bias_lds[i] = (col_lo + i < col_hi) ? p.bias[col_lo + i] : 0.f;
+  for (int i = tid; i < MAX_SCALE; i += 256) scale_lds[i] = (p.col_scale && col_lo + i < p.scale_cols) ? p.col_scale[col_lo + i] : 1.f;
+  __syncthreads();
+  const char* wp = reinterpret_cast<const char*>(p.wpack);
+  const unsigned lane_off = (unsigned)lane * 16u;
+  auto issue = [&](int st) {             // stage st -> ring slot (st - st_lo) % NST
+    char* sb = smem + ((st - st_lo) % NST) * STAGE_B;
+    const char* cb = wp + (size_t)st * STAGE_B;
+#pragma unroll
+    for (int k = 0; k < STAGE_PIECES / NW; ++k) {
+      const int q = wave + NW * k;
+      const char* src = sgpr_ptr(cb + q * 1024);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + lane_off), (lds_ptr_t)(sb + q * 1024), 16, 0, 0);
+    }
+  };
+  const int r1 = pi23(fr);
+  const int rd_perm = r1 * 32 + ((fh ^ ((r1 >> 3) & 1)) << 4);     // row-major outputs: MFMA row i <-> column pi23(i)
+  const int rd_nat = fr * 32 + ((fh ^ ((fr >> 3) & 1)) << 4);      // transposed outputs: natural order
+
+  issue(st_lo);
+#pragma nounroll
+  for (int st = st_lo; st < st_hi; ++st) {
+    // Stage st landed.  Its 9 pieces were the first vector-memory operations of the previous iteration; behind them every
+    // chunk issued at least 2 more (2 f16 stores, or 4 transposed stores, or 4 residual loads + 4 f32 stores).  vmcnt retires
+    // in order, so leaving the 2 youngest per chunk outstanding never skips a piece and does not wait for the last store
+    // acknowledgements.  Ragged M: some waves store nothing -> drain.
+    if (st == st_lo || (p.M & 127)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first stage: nothing was issued behind its pieces
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CPS) : "memory");
+    __builtin_amdgcn_s_barrier();                         // ... for every wave; everyone is done with the other slot
+    if (st + 1 < st_hi) issue(st + 1);
+    const char* sb = smem + ((st - st_lo) % NST) * STAGE_B;
+#pragma unroll
+    for (int c = 0; c < CPS; ++c) {
+      const int n0 = (st * CPS + c) * 32;
+      if (n0 >= p.N) break;                               // wave-uniform (zero-padded tail of the packed image)
+      const bool trans = n0 >= p.n_split;
+      const char* sW = sb + c * KS * 1024 + (trans ? rd_nat : rd_perm);
+      // the bias is the initial accumulator (row-major: register 8 ks + e <-> column n0 + 16 ks + 8 fh + e; transposed: column fr)
+      f32x16 sa;
+      if (!trans) {
+        const float* bp = bias_lds + (n0 - col_lo) + 8 * fh;       // zero past N
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(bp + 16), b3 = *reinterpret_cast<const f32x4*>(bp + 20);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sa[e] = b0[e]; sa[4 + e] = b1[e]; sa[8 + e] = b2[e]; sa[12 + e] = b3[e]; }
+      } else {
+        const float bt = bias_lds[n0 - col_lo + fr];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sa[r] = bt;
+      }
+      {
+        constexpr int NB = (KS + FB - 1) / FB;
+        half8 cur[FB], nxt[FB];
+#pragma unroll
+        for (int j = 0; j < FB; ++j)
+          if (j < KS) cur[j] = *reinterpret_cast<const half8*>(sW + j * 1024);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+          for (int j = 0; j < FB; ++j)
+            if ((b + 1) * FB + j < KS) nxt[j] = *reinterpret_cast<const half8*>(sW + ((b + 1) * FB + j) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+          if (!trans) {
+#pragma unroll
+            for (int j = 0; j < FB; ++j)
+              if (b * FB + j < KS) sa = mfma32(cur[j], xf[b * FB + j], sa);
+          } else {
+#pragma unroll
+            for (int j = 0; j < FB; ++j)
+              if (b * FB + j < KS) sa = mfma32(xf[b * FB + j], cur[j], sa);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < FB; ++j) cur[j] = nxt[j];
+        }
+      }
+      // ---- epilogue on the accumulator tile
+      if (!trans) {
+        // register 8 ks + e  <->  column n0 + 16 ks + 8 fh + e of token fr
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = (p.act == ACT_GELU) ? gelu_erf_fast(sa[r]) : sa[r];
+        if (n0 < p.scale_cols) {                                   // wave-uniform; scale_cols % 32 == 0
+          const float* cp = scale_lds + (n0 - col_lo) + 8 * fh;
+          const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
+          const f32x4 c2 = *reinterpret_cast<const f32x4*>(cp + 16), c3 = *reinterpret_cast<const f32x4*>(cp + 20);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] *= c0[e]; v[4 + e] *= c1[e]; v[8 + e] *= c2[e]; v[12 + e] *= c3[e]; }
+        }
+        const int tok = tok0 + fr;
+        if (tok < p.M) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const int n = n0 + 16 * ks + 8 * fh;
+            if (n >= p.N) continue;
+            if (p.out32) {
+              float* op = p.out32 + (size_t)tok * p.ld32 + n;
+              f32x4 a = {v[8 * ks], v[8 * ks + 1], v[8 * ks + 2], v[8 * ks + 3]};
+              f32x4 b = {v[8 * ks + 4], v[8 * ks + 5], v[8 * ks + 6], v[8 * ks + 7]};
+              if (p.res) {
+                const float* rp = p.res + (size_t)tok * p.ldres + n;
+                const f32x4 ra = *reinterpret_cast<const f32x4*>(rp), rb = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] += ra[e]; b[e] += rb[e]; }
+              }
+              *reinterpret_cast<f32x4*>(op) = a;
+              *reinterpret_cast<f32x4*>(op + 4) = b;
+            }
+            if (p.out16) {
+              half8 h;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) h[e] = (half_t)v[8 * ks + e];
+              *reinterpret_cast<half8*>(p.out16 + (size_t)tok * p.ld16 + n) = h;
+            }
+          }
+        }
+      } else {
+        // S = X W^T: register r <-> token tok0 + (r & 3) + 8 (r >> 2) + 4 fh of column n0 + fr
+        if (n0 + fr < p.N) {
+        half_t* op = p.outT16 + (size_t)(n0 - p.n_split + fr) * p.ldT16 + tok0 + 4 * fh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          half4 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h[e] = (half_t)sa[4 * g + e];
+          if (tok0 + 8 * g + 4 * fh + 3 < p.M) *reinterpret_cast<half4*>(op + 8 * g) = h;
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (tok0 + 8 * g + 4 * fh + e < p.M) op[8 * g + e] = h[e];
+          }
+        }
+        }
+      }
+    }
+  }
+}
+
+// one thread per 16-B unit of the packed image: stage = 36 pieces = CPS chunks x KS k-steps; piece (c, s) holds rows
+// n = 32 (st CPS + c) + row of W, k = 16 s + 8 h .. + 7 at byte 32 row + 16 (h ^ ((row >> 3) & 1)); rows past N are zero
+template <int K>
+__global__ void gemm_xs_pack_kernel(const half_t* __restrict__ w, int N, int ldw, half_t* __restrict__ out, long units) {
+  constexpr int KS = K / 16;
+  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= units) return;
+  const long piece = u >> 6;
+  const int l = (int)(u & 63), row = l >> 1, h = (l & 1) ^ ((row >> 3) & 1);
+  const long chunk = piece / KS;
+  const int s = (int)(piece - chunk * KS);
+  const long n = chunk * 32 + row;
+  half8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (half_t)0.f;
+  if (n < N) v = *reinterpret_cast<const half8*>(w + n * ldw + 16 * s + 8 * h);
+  *reinterpret_cast<half8*>(out + u * 8) = v;
+}
+
+template <int K>
+hipError_t launch_k(const GemmXsParams& p, hipStream_t s) {
+  constexpr int CPS = STAGE_PIECES / (K / 16);
+  const int nstages = (p.N + 32 * CPS - 1) / (32 * CPS);
+  const int tb = (p.M + 32 * NW - 1) / (32 * NW);
+  // column splits: fill the chip with two workgroups per CU (512 slots) at least once, never more splits than stages
+  int splits = (2 * 256 + tb - 1) / tb;
+  if (p.splits > 0) splits = p.splits;
+  const int max_stages = MAX_COLS / (32 * CPS);                         // bias table: at most MAX_COLS columns per workgroup
+  splits = std::max(splits, (nstages + max_stages - 1) / max_stages);
+  splits = std::max(1, std::min(splits, nstages));
+  if ((nstages + splits - 1) / splits > max_stages) return hipErrorInvalidValue;
+  gemm_xs_kernel<K><<<dim3(tb, splits), dim3(64 * NW), LDS_B, s>>>(p);
+  return hipGetLastError();
+}
+template <int K>
+hipError_t attr_k() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+}
+}  // namespace
+
+hipError_t gemm_xs_init() {
+  hipError_t e[3] = {attr_k<144>(), attr_k<288>(), attr_k<576>()};
+  for (int i = 0; i < 3; ++i)
+    if (e[i] != hipSuccess) return e[i];
+  return hipSuccess;
+}
+
+bool gemm_xs_supported(int N, int K) { return (K == 144 || K == 288 || K == 576) && N % 8 == 0 && N >= 8; }
+
+size_t gemm_xs_pack_bytes(int N, int K) {
+  if (!gemm_xs_supported(N, K)) return 0;
+  const int cps = STAGE_PIECES / (K / 16);
+  const int nstages = (N + 32 * cps - 1) / (32 * cps);
+  return (size_t)nstages * STAGE_B;
+}
+
+hipError_t gemm_xs_pack(const half_t* w, int N, int K, int ldw, half_t* wpack, hipStream_t s) {
+  const long units = (long)(gemm_xs_pack_bytes(N, K) / 16);
+  if (units == 0) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((units + 255) / 256)), block(256);
+  if (K == 144) gemm_xs_pack_kernel<144><<<grid, block, 0, s>>>(w, N, ldw, wpack, units);
+  else if (K == 288) gemm_xs_pack_kernel<288><<<grid, block, 0, s>>>(w, N, ldw, wpack, units);
+  else gemm_xs_pack_kernel<576><<<grid, block, 0, s>>>(w, N, ldw, wpack, units);
+  return hipGetLastError();
+}
+
+hipError_t gemm_xs_launch(const GemmXsParams& p, int K, hipStream_t s) {
+  if (p.M <= 0) return hipSuccess;
+  if (!gemm_xs_supported(p.N, K) || (p.ldx & 7) || (p.n_split < p.N && (p.n_split & 31)) || !p.bias) return hipErrorInvalidValue;
+  if (p.n_split < p.N && (!p.outT16 || (p.ldT16 & 3))) return hipErrorInvalidValue;
+  if (p.col_scale && ((p.scale_cols & 31) || p.scale_cols > MAX_SCALE || p.scale_cols > p.n_split)) return hipErrorInvalidValue;
+  if (p.out16 && (p.ld16 & 7)) return hipErrorInvalidValue;
+  if (p.out32 && ((p.ld32 & 3) || (p.res && (p.ldres & 3)))) return hipErrorInvalidValue;
+  switch (K) {
+    case 144: return launch_k<144>(p, s);
+    case 288: return launch_k<288>(p, s);
+    default: return launch_k<576>(p, s);
+  }
+}

@@ -111,3 +111,24 @@ def test_mlp_fused(eng, M, C):
     check(f"mlp_fused {M}x{C}", out, ref.float(), 1e-4, 2e-4)
     two, _ = eng.debug_mlp(xn, W1, b1, W2, b2, x, fused=False)
     check(f"mlp_fused vs two-GEMM {M}x{C}", out, two, 1e-4, 2e-4)
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [
+    (4096, 1728, 576, 0, False), (1000, 576, 576, 0, True), (4096, 2304, 576, 1, False), (2048, 432, 144, 0, False),
+    (3000, 864, 288, 0, True), (512, 1152, 288, 1, False), (130, 144, 144, 0, True), (256, 40, 576, 0, False),
+])
+def test_gemm_xs(eng, M, N, K, act, res):
+    """X-stationary short-K GEMM (gemm_xs.hip; QKV / projection / fc1 of Hiera stages 1-3) vs fp64 PyTorch on f16-rounded
+    operands: row-major f32 output, optional erf-GELU and residual, ragged M and N (N % 8 == 0)."""
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K + 1)
+    A = r16(torch.randn(M, K, generator=g)).cuda()
+    W = r16(torch.randn(N, K, generator=g) / math.sqrt(K)).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).cuda() if res else None
+    out = eng.debug_gemm(A, W, b, act, R, tile_hint=30)
+    ref = A.double() @ W.double().t() + b.double()
+    if act == 1:
+        ref = F.gelu(ref)
+    if res:
+        ref = ref + R.double()
+    check(f"gemm_xs {M}x{N}x{K} act{act}", out, ref.float(), 1e-4, 1e-5)

@@ -18,6 +18,10 @@ eng = Engine("large", state_dict=None)
 for name, M, N, K, mode in shapes:
     row = f"{name:8s} M={M:7d} N={N:5d} K={K:5d} m{mode}:"
     for h in HINTS:
-        ms = eng.debug_gemm_bench(M, N, K, 10, (MODE if MODE >= 0 else mode) | (h << 4))
+        try:
+            ms = eng.debug_gemm_bench(M, N, K, 10, (MODE if MODE >= 0 else mode) | (h << 4))
+        except RuntimeError:
+            row += f"  h{h}:      n/a"
+            continue
         row += f"  h{h}: {ms*1e3:8.1f}us {2.0*M*N*K/ms/1e9:7.1f}TF"
     print(row, flush=True)
