@@ -67,7 +67,8 @@ static void prof_end(ProfAcc& a, hipStream_t s, hipEvent_t e0, hipEvent_t e1, do
 static bool xs_eligible(const sam2mi_ctx* ctx, const GemmParams& p) {
   return ctx->use_xs && p.xs_pack && p.tile_hint == 0 && p.M >= 16384 && p.lda == p.K && gemm_xs_supported(p.N, p.K) &&
          (p.act == ACT_NONE || p.act == ACT_GELU) && p.rope_cols == 0 && p.res_mod == 0 && !p.outT32 && (p.n_split >= p.N || (p.n_split & 31) == 0) &&
-         !(p.out32 && p.out16) && (p.out32 || p.out16) && (!p.res || p.out32) && p.bias && (!p.col_scale || p.xs_scale_cols > 0);
+         !(p.out32 && p.out16) && (p.out32 || p.out16) && (!p.res || p.out32) && p.bias &&
+         (!p.col_scale || (p.xs_scale_cols > 0 && p.xs_scale_cols <= 576 && (p.xs_scale_cols + 31) / 32 * 32 <= p.n_split));
 }
 int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p) {
   if (xs_eligible(ctx, p)) {
@@ -399,7 +400,7 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
       b.proj = pk.lin16(p + "attn.proj");
       b.fc1 = pk.lin16(p + "mlp.layers.0");
       b.fc2 = pk.lin16(p + "mlp.layers.1");
-      for (Lin16* L : {&b.qkv, &b.proj, &b.fc1}) {       // stages 1-3: short-K linears also in the X-stationary kernel's piece order
+      for (Lin16* L : {&b.qkv, &b.fc1}) {       // stages 1-3: QKV and fc1 also in the X-stationary kernel's piece order (the projection, N = K, is not faster there)
         if (!pk.ok || !L->w || !gemm_xs_supported(L->N, L->K) || (L == &b.fc1 && mlp_fused_supported(b.dim_out))) continue;
         L->xs_pack = (half_t*)dalloc(ctx, gemm_xs_pack_bytes(L->N, L->K));
         if (!L->xs_pack || gemm_xs_pack(L->w, L->N, L->K, L->K, L->xs_pack, nullptr) != hipSuccess) pk.ok = false;

@@ -8,7 +8,7 @@ struct GemmXsParams {
   const half_t* wpack;             // weight [N, K] in piece order (gemm_xs_pack)
   const float* bias;               // [N]
   const float* col_scale;          // [>= scale_cols] or null: v *= col_scale[n] after bias / activation, columns n < scale_cols
-  int scale_cols;                  //   (the q pre-scale of a QKV projection); % 32 == 0, <= 576, <= n_split
+  int scale_cols;                  //   (the q pre-scale of a QKV projection); <= 576, rounded up to 32 <= n_split
   int act;                         // ACT_NONE or ACT_GELU (row-major columns only)
   int M, N;                        // N % 8 == 0
   int n_split;                     // columns >= n_split go to outT16 (multiple of 32; == N: none)

@@ -16,6 +16,7 @@
 //     its MFMA chain (two workgroups of 4 waves per CU).
 // Grid = (M / 128 token blocks) x (column splits): the column range is split so that the chip holds two waves per SIMD.
 #include "gemm_xs.h"
+#include <type_traits>
 
 namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -36,9 +37,10 @@ constexpr int NST = 2;
 constexpr int MAX_COLS = 1152;           // output columns per workgroup (bias table in LDS)
 constexpr int MAX_SCALE = 576;           // of which at most this many leading ones carry a column scale
 constexpr int LDS_B = NST * STAGE_B + (MAX_COLS + MAX_SCALE) * 4;       // 80,640 B: two workgroups per CU
-template <int K> constexpr int frag_batch() { return K == 576 ? 4 : (K == 288 ? 6 : 5); }   // fragments per LDS read batch (double-buffered)
+template <int K> constexpr int frag_batch() { return K == 144 ? 5 : 6; }   // fragments per LDS read batch (double-buffered)
 
-template <int K>
+// GELU: erf-GELU on the row-major columns; F32: f32 output (+ residual) instead of f16 for the row-major columns
+template <int K, bool GELU, bool F32>
 __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmXsParams p) {
   constexpr int KS = K / 16;             // k-steps = pieces per chunk
   constexpr int CPS = STAGE_PIECES / KS; // chunks (of 32 output columns) per stage
@@ -86,6 +88,102 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmXsParams p) {
   const int rd_perm = r1 * 32 + ((fh ^ ((r1 >> 3) & 1)) << 4);     // row-major outputs: MFMA row i <-> column pi23(i)
   const int rd_nat = fr * 32 + ((fh ^ ((fr >> 3) & 1)) << 4);      // transposed outputs: natural order
 
+  // One chunk = one 32x32 accumulator tile over all of K.  The two variants are separate straight-line bodies (a branch
+  // inside the MFMA chain would cut the scheduling region at every fragment batch).
+  // chain<SWAP>: acc = W_chunk . X^T (SWAP = false) or X . W_chunk^T (SWAP = true), fragments read in double-buffered batches
+  auto chain = [&](const char* sW, f32x16& sa, auto swap) {
+    constexpr bool SWAP = decltype(swap)::value;
+    constexpr int NB = (KS + FB - 1) / FB;
+    half8 cur[FB], nxt[FB];
+#pragma unroll
+    for (int j = 0; j < FB; ++j)
+      if (j < KS) cur[j] = *reinterpret_cast<const half8*>(sW + j * 1024);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int j = 0; j < FB; ++j)
+        if ((b + 1) * FB + j < KS) nxt[j] = *reinterpret_cast<const half8*>(sW + ((b + 1) * FB + j) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < FB; ++j)
+        if (b * FB + j < KS) sa = SWAP ? mfma32(xf[b * FB + j], cur[j], sa) : mfma32(cur[j], xf[b * FB + j], sa);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < FB; ++j) cur[j] = nxt[j];
+    }
+  };
+  // row-major columns: S^T = W_chunk X^T; register 8 ks + e <-> column n0 + 16 ks + 8 fh + e of token fr
+  auto chunk_row = [&](const char* sW, int n0) {
+    f32x16 sa;
+    {
+      const float* bp = bias_lds + (n0 - col_lo) + 8 * fh;       // the bias is the initial accumulator (zero past N)
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(bp + 16), b3 = *reinterpret_cast<const f32x4*>(bp + 20);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { sa[e] = b0[e]; sa[4 + e] = b1[e]; sa[8 + e] = b2[e]; sa[12 + e] = b3[e]; }
+    }
+    chain(sW, sa, std::false_type{});
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = GELU ? gelu_erf_fast(sa[r]) : sa[r];
+    if (n0 < p.scale_cols) {                                   // wave-uniform; the table holds 1 from scale_cols on
+      const float* cp = scale_lds + (n0 - col_lo) + 8 * fh;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
+      const f32x4 c2 = *reinterpret_cast<const f32x4*>(cp + 16), c3 = *reinterpret_cast<const f32x4*>(cp + 20);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] *= c0[e]; v[4 + e] *= c1[e]; v[8 + e] *= c2[e]; v[12 + e] *= c3[e]; }
+    }
+    const int tok = tok0 + fr;
+    if (tok < p.M) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int n = n0 + 16 * ks + 8 * fh;
+        if (n >= p.N) continue;                                // N % 8 == 0: an 8-column group is valid or wholly past N
+        if (F32) {
+          float* op = p.out32 + (size_t)tok * p.ld32 + n;
+          f32x4 a = {v[8 * ks], v[8 * ks + 1], v[8 * ks + 2], v[8 * ks + 3]};
+          f32x4 b = {v[8 * ks + 4], v[8 * ks + 5], v[8 * ks + 6], v[8 * ks + 7]};
+          if (p.res) {
+            const float* rp = p.res + (size_t)tok * p.ldres + n;
+            const f32x4 ra = *reinterpret_cast<const f32x4*>(rp), rb = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] += ra[e]; b[e] += rb[e]; }
+          }
+          *reinterpret_cast<f32x4*>(op) = a;
+          *reinterpret_cast<f32x4*>(op + 4) = b;
+        } else {
+          half8 h;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) h[e] = (half_t)v[8 * ks + e];
+          *reinterpret_cast<half8*>(p.out16 + (size_t)tok * p.ld16 + n) = h;
+        }
+      }
+    }
+  };
+  // transposed columns (V^T): S = X W_chunk^T; register r <-> token tok0 + (r & 3) + 8 (r >> 2) + 4 fh of column n0 + fr
+  auto chunk_trans = [&](const char* sW, int n0) {
+    f32x16 sa;
+    const float bt = bias_lds[n0 - col_lo + fr];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sa[r] = bt;
+    chain(sW, sa, std::true_type{});
+    if (n0 + fr < p.N) {
+      half_t* op = p.outT16 + (size_t)(n0 - p.n_split + fr) * p.ldT16 + tok0 + 4 * fh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)sa[4 * g + e];
+        if (tok0 + 8 * g + 4 * fh + 3 < p.M) *reinterpret_cast<half4*>(op + 8 * g) = h;
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (tok0 + 8 * g + 4 * fh + e < p.M) op[8 * g + e] = h[e];
+        }
+      }
+    }
+  };
+
   issue(st_lo);
 #pragma nounroll
   for (int st = st_lo; st < st_hi; ++st) {
@@ -102,105 +200,8 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmXsParams p) {
     for (int c = 0; c < CPS; ++c) {
       const int n0 = (st * CPS + c) * 32;
       if (n0 >= p.N) break;                               // wave-uniform (zero-padded tail of the packed image)
-      const bool trans = n0 >= p.n_split;
-      const char* sW = sb + c * KS * 1024 + (trans ? rd_nat : rd_perm);
-      // the bias is the initial accumulator (row-major: register 8 ks + e <-> column n0 + 16 ks + 8 fh + e; transposed: column fr)
-      f32x16 sa;
-      if (!trans) {
-        const float* bp = bias_lds + (n0 - col_lo) + 8 * fh;       // zero past N
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
-        const f32x4 b2 = *reinterpret_cast<const f32x4*>(bp + 16), b3 = *reinterpret_cast<const f32x4*>(bp + 20);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { sa[e] = b0[e]; sa[4 + e] = b1[e]; sa[8 + e] = b2[e]; sa[12 + e] = b3[e]; }
-      } else {
-        const float bt = bias_lds[n0 - col_lo + fr];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sa[r] = bt;
-      }
-      {
-        constexpr int NB = (KS + FB - 1) / FB;
-        half8 cur[FB], nxt[FB];
-#pragma unroll
-        for (int j = 0; j < FB; ++j)
-          if (j < KS) cur[j] = *reinterpret_cast<const half8*>(sW + j * 1024);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-#pragma unroll
-          for (int j = 0; j < FB; ++j)
-            if ((b + 1) * FB + j < KS) nxt[j] = *reinterpret_cast<const half8*>(sW + ((b + 1) * FB + j) * 1024);
-          __builtin_amdgcn_sched_barrier(0);
-          if (!trans) {
-#pragma unroll
-            for (int j = 0; j < FB; ++j)
-              if (b * FB + j < KS) sa = mfma32(cur[j], xf[b * FB + j], sa);
-          } else {
-#pragma unroll
-            for (int j = 0; j < FB; ++j)
-              if (b * FB + j < KS) sa = mfma32(xf[b * FB + j], cur[j], sa);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < FB; ++j) cur[j] = nxt[j];
-        }
-      }
-      // ---- epilogue on the accumulator tile
-      if (!trans) {
-        // register 8 ks + e  <->  column n0 + 16 ks + 8 fh + e of token fr
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = (p.act == ACT_GELU) ? gelu_erf_fast(sa[r]) : sa[r];
-        if (n0 < p.scale_cols) {                                   // wave-uniform; scale_cols % 32 == 0
-          const float* cp = scale_lds + (n0 - col_lo) + 8 * fh;
-          const f32x4 c0 = *reinterpret_cast<const f32x4*>(cp), c1 = *reinterpret_cast<const f32x4*>(cp + 4);
-          const f32x4 c2 = *reinterpret_cast<const f32x4*>(cp + 16), c3 = *reinterpret_cast<const f32x4*>(cp + 20);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] *= c0[e]; v[4 + e] *= c1[e]; v[8 + e] *= c2[e]; v[12 + e] *= c3[e]; }
-        }
-        const int tok = tok0 + fr;
-        if (tok < p.M) {
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const int n = n0 + 16 * ks + 8 * fh;
-            if (n >= p.N) continue;
-            if (p.out32) {
-              float* op = p.out32 + (size_t)tok * p.ld32 + n;
-              f32x4 a = {v[8 * ks], v[8 * ks + 1], v[8 * ks + 2], v[8 * ks + 3]};
-              f32x4 b = {v[8 * ks + 4], v[8 * ks + 5], v[8 * ks + 6], v[8 * ks + 7]};
-              if (p.res) {
-                const float* rp = p.res + (size_t)tok * p.ldres + n;
-                const f32x4 ra = *reinterpret_cast<const f32x4*>(rp), rb = *reinterpret_cast<const f32x4*>(rp + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { a[e] += ra[e]; b[e] += rb[e]; }
-              }
-              *reinterpret_cast<f32x4*>(op) = a;
-              *reinterpret_cast<f32x4*>(op + 4) = b;
-            }
-            if (p.out16) {
-              half8 h;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) h[e] = (half_t)v[8 * ks + e];
-              *reinterpret_cast<half8*>(p.out16 + (size_t)tok * p.ld16 + n) = h;
-            }
-          }
-        }
-      } else {
-        // S = X W^T: register r <-> token tok0 + (r & 3) + 8 (r >> 2) + 4 fh of column n0 + fr
-        if (n0 + fr < p.N) {
-        half_t* op = p.outT16 + (size_t)(n0 - p.n_split + fr) * p.ldT16 + tok0 + 4 * fh;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          half4 h;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) h[e] = (half_t)sa[4 * g + e];
-          if (tok0 + 8 * g + 4 * fh + 3 < p.M) *reinterpret_cast<half4*>(op + 8 * g) = h;
-          else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (tok0 + 8 * g + 4 * fh + e < p.M) op[8 * g + e] = h[e];
-          }
-        }
-        }
-      }
+      if (n0 < p.n_split) chunk_row(sb + c * KS * 1024 + rd_perm, n0);
+      else chunk_trans(sb + c * KS * 1024 + rd_nat, n0);
     }
   }
 }
@@ -236,12 +237,20 @@ hipError_t launch_k(const GemmXsParams& p, hipStream_t s) {
   splits = std::max(splits, (nstages + max_stages - 1) / max_stages);
   splits = std::max(1, std::min(splits, nstages));
   if ((nstages + splits - 1) / splits > max_stages) return hipErrorInvalidValue;
-  gemm_xs_kernel<K><<<dim3(tb, splits), dim3(64 * NW), LDS_B, s>>>(p);
+  const dim3 grid(tb, splits), block(64 * NW);
+  if (p.out32 && p.act == ACT_GELU) gemm_xs_kernel<K, true, true><<<grid, block, LDS_B, s>>>(p);      // tests only
+  else if (p.out32) gemm_xs_kernel<K, false, true><<<grid, block, LDS_B, s>>>(p);
+  else if (p.act == ACT_GELU) gemm_xs_kernel<K, true, false><<<grid, block, LDS_B, s>>>(p);
+  else gemm_xs_kernel<K, false, false><<<grid, block, LDS_B, s>>>(p);
   return hipGetLastError();
 }
 template <int K>
 hipError_t attr_k() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+  return e;
 }
 }  // namespace
 
@@ -275,8 +284,9 @@ hipError_t gemm_xs_launch(const GemmXsParams& p, int K, hipStream_t s) {
   if (p.M <= 0) return hipSuccess;
   if (!gemm_xs_supported(p.N, K) || (p.ldx & 7) || (p.n_split < p.N && (p.n_split & 31)) || !p.bias) return hipErrorInvalidValue;
   if (p.n_split < p.N && (!p.outT16 || (p.ldT16 & 3))) return hipErrorInvalidValue;
-  if (p.col_scale && ((p.scale_cols & 31) || p.scale_cols > MAX_SCALE || p.scale_cols > p.n_split)) return hipErrorInvalidValue;
+  if (p.col_scale && (p.scale_cols <= 0 || p.scale_cols > MAX_SCALE || (p.scale_cols + 31) / 32 * 32 > p.n_split)) return hipErrorInvalidValue;
   if (p.out16 && (p.ld16 & 7)) return hipErrorInvalidValue;
+  if (!p.out32 && !p.out16) return hipErrorInvalidValue;
   if (p.out32 && ((p.ld32 & 3) || (p.res && (p.ldres & 3)))) return hipErrorInvalidValue;
   switch (K) {
     case 144: return launch_k<144>(p, s);
