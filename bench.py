@@ -12,9 +12,10 @@ fps = frames / time).  W warm-up steps, then K timed steps between barrier + tor
 time = MAX over ranks; value = N * K * frames / time (weak scaling: independent clips, no data-path collective).
 
 The JSON line also carries
-  roofline     - the dominant kernel (the MFMA GEMM `gemm_v2_kernel`): algorithmic FLOPs / launch time, measured
-                 with HIP events around every GEMM launch on its own stream in a second, un-timed pass of the same
-                 K steps (sam2mi_profile_enable), vs the 2.5 PFLOP/s dense f16 MFMA peak;
+  roofline     - the dominant kernel (whichever of the three MFMA GEMM kernels - tiled `gemm_v2_kernel`, X-stationary
+                 `gemm_xs_kernel`, fused-MLP `mlp_fused_kernel` - takes the most time): algorithmic FLOPs / launch time,
+                 measured with HIP events around every launch on its own stream in a second, un-timed pass of the same
+                 K steps (sam2mi_profile_enable), vs the 2.5 PFLOP/s dense f16 MFMA peak; the other two beside it;
   cpu_baseline - the CPU oracle (oracle/sam2_ref.py, a port of the reference's torch backend) timed on this
                  box's host cores on the first frames of the same clip (rank 0, N = 1 only).
 """
@@ -36,13 +37,13 @@ PEAK_F16_TFLOPS = 2500.0                 # dense f16/bf16 MFMA peak of MI355X (M
 CLIP_GFLOP_PROPAGATE = 240450.0          # algorithmic GFLOP of one 100-frame propagate loop
 
 
-def _pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE and
-    WRITE_SIZE runs, gfx950 x2 fetch correction; profiles/r01_c_pmc_traffic.md).  PMC collection cannot run inside the
-    timed process, so this is the last committed measurement, or None."""
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (separate FETCH_SIZE and WRITE_SIZE
+    runs, gfx950 x2 fetch correction; profiles/*_pmc_traffic.md).  PMC collection cannot run inside the timed process, so
+    this is the last committed measurement, or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["gemm_v2_kernel"]["bytes_per_launch"]
+            return json.load(f)[kernel]["bytes_per_launch"]
     except Exception:
         return None
 
@@ -122,13 +123,29 @@ def main():
         pr = pred.engine.profile_read()
         pred.engine.profile_enable(False)
         pred.overlap_encode = overlap
-        ach = pr["gemm_flops"] / (pr["gemm_ms"] * 1e-3) / 1e12 if pr["gemm_ms"] > 0 else 0.0
+        # the MFMA GEMM work of the path runs in three hand-written kernels; the roofline object is the one that takes the most
+        # time, the other two are listed beside it ("kernels"), all measured the same way in the same pass
+        fam = {"gemm_v2_kernel": ("gemm", "tiled LDS-DMA GEMM (all tile instantiations): every linear not listed below"),
+               "gemm_xs_kernel": ("xs", "X-stationary short-K GEMM: QKV of stages 1-3, fc1 of stage 3"),
+               "mlp_fused_kernel": ("mlp", "fused fc1+GELU+fc2+residual of stages 1-2")}
+        kern = {}
+        for name, (key, what) in fam.items():
+            ms, fl, n = pr[f"{key}_ms"], pr[f"{key}_flops"], int(pr[f"{key}_launches"])
+            if n == 0:
+                continue
+            kern[name] = {"what": what, "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
+                          "launches": n, "gflop_per_launch": round(fl / n / 1e9, 3), "avg_launch_us": round(ms * 1e3 / n, 2),
+                          "share_of_timed_region": round(ms * 1e-3 / dt, 3)}
+        dom = max(kern, key=lambda k: kern[k]["share_of_timed_region"])
+        tot_ms = sum(pr[f"{fam[k][0]}_ms"] for k in kern)
+        tot_fl = sum(pr[f"{fam[k][0]}_flops"] for k in kern)
         roofline = {
-            "bound": "mfma", "kernel": "gemm_v2_kernel", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": _pmc_traffic(),
-            "launches": int(pr["gemm_launches"]), "gflop_per_launch": round(pr["gemm_flops"] / max(pr["gemm_launches"], 1) / 1e9, 3),
-            "avg_launch_us": round(pr["gemm_ms"] * 1e3 / max(pr["gemm_launches"], 1), 2),
-            "gemm_share_of_timed_region": round(pr["gemm_ms"] * 1e-3 / dt, 3),
+            "bound": "mfma", "kernel": dom, "achieved": kern[dom]["achieved"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+            "frac": kern[dom]["frac"], "traffic": _pmc_traffic(dom),
+            "launches": kern[dom]["launches"], "gflop_per_launch": kern[dom]["gflop_per_launch"], "avg_launch_us": kern[dom]["avg_launch_us"],
+            "kernels": kern,
+            "all_gemm_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
+                                 "share_of_timed_region": round(tot_ms * 1e-3 / dt, 3)},
             "attention_kernels": {"achieved": round(pr["attn_flops"] / max(pr["attn_ms"] * 1e-3, 1e-9) / 1e12, 2),
                                   "launches": int(pr["attn_launches"]), "ms": round(pr["attn_ms"], 2)},
             "whole_path": {"algorithmic_gflop_per_step": CLIP_GFLOP_PROPAGATE * args.frames / 100.0,

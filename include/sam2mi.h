@@ -196,6 +196,8 @@ int sam2mi_profile_read(sam2mi_ctx* ctx, double* gemm_ms, double* gemm_flops, in
 int sam2mi_profile_read_mlp(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* launches);
 /* Same for the X-stationary short-K GEMM (gemm_xs_kernel: QKV / projection / fc1 of Hiera stages 1-3; flops = 2 M N K). */
 int sam2mi_profile_read_xs(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* launches);
+/* Same for the accumulator-stationary N = 576 GEMM (gemm_ks_kernel: projection / fc2 of Hiera stage 3). */
+int sam2mi_profile_read_ks(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* launches);
 
 /* Debug/test entry points: single kernels behind the C ABI (used by tests/test_kernels_gpu.py). */
 int sam2mi_debug_gemm(sam2mi_ctx* ctx, void* stream, const float* A, const float* W, const float* bias, int M, int N, int K,

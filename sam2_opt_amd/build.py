@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libsam2mi.so")
-SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "gemm4.hip", "mlp_fused.hip", "gemm_xs.hip", "attn_hiera.hip", "attn_flash256.hip", "attn_small.hip", "elementwise.hip", "convs.hip",
+SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "gemm4.hip", "mlp_fused.hip", "gemm_xs.hip", "gemm_ks.hip", "attn_hiera.hip", "attn_flash256.hip", "attn_small.hip", "elementwise.hip", "convs.hip",
            "heads.hip", "postproc.hip", "engine_core.hip", "engine_encoder.hip", "engine_track.hip", "engine_abi.hip", "engine_debug.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 

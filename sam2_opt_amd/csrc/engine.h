@@ -12,6 +12,7 @@
 #include "gemm.h"
 #include "kernels.h"
 #include "gemm_xs.h"
+#include "gemm_ks.h"
 #include "mlp_fused.h"
 
 struct HostW {
@@ -24,6 +25,7 @@ struct Lin16 {            // MFMA operand: f16 weight [N, K] (nn.Linear layout),
   float* b = nullptr;
   int N = 0, K = 0;
   half_t* xs_pack = nullptr;   // same weight in the piece order of the X-stationary GEMM (Hiera stages 1-3, K <= 576)
+  half_t* ks_pack = nullptr;   // ... of the accumulator-stationary GEMM (N = 576: stage-3 projection and fc2)
 };
 struct Lin32 {            // tiny fp32 linear for the token-side heads
   float* w = nullptr;
@@ -178,7 +180,8 @@ struct sam2mi_ctx {
 
   // ---- profiling
   bool prof_on = false;
-  ProfAcc prof_gemm, prof_attn, prof_mlp, prof_xs;
+  ProfAcc prof_gemm, prof_attn, prof_mlp, prof_xs, prof_ks;
+  bool use_ks = false;             // accumulator-stationary GEMM for stage-3 fc2 (experimental, SAM2MI_KS=1; parity-tested, not faster end to end)
   bool use_xs = true;              // X-stationary GEMM for K <= 576 linears of the encoder (SAM2MI_NO_XS=1: tiled kernel)
   bool use_fused_mlp = true;       // stages with C <= 288: one fused fc1-GELU-fc2 kernel (SAM2MI_NO_FUSED_MLP=1: two GEMMs, for A/B runs)
 };

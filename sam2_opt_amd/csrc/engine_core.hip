@@ -70,7 +70,19 @@ static bool xs_eligible(const sam2mi_ctx* ctx, const GemmParams& p) {
          !(p.out32 && p.out16) && (p.out32 || p.out16) && (!p.res || p.out32) && p.bias &&
          (!p.col_scale || (p.xs_scale_cols > 0 && p.xs_scale_cols <= 576 && (p.xs_scale_cols + 31) / 32 * 32 <= p.n_split));
 }
+static bool ks_eligible(const sam2mi_ctx* ctx, const GemmParams& p) {
+  return ctx->use_ks && p.ks_pack && p.tile_hint == 0 && p.M >= 16384 && gemm_ks_supported(p.N, p.K) && p.act == ACT_NONE &&
+         !p.col_scale && p.rope_cols == 0 && p.res_mod == 0 && p.out32 && !p.out16 && !p.outT16 && !p.outT32 && p.n_split >= p.N && p.bias;
+}
 int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p) {
+  if (ks_eligible(ctx, p)) {
+    GemmKsParams k{p.A, p.lda, p.ks_pack, p.bias, p.res, p.ldres, p.out32, p.ld32, p.M, p.K};
+    hipEvent_t e0, e1;
+    if (ctx->prof_on) prof_begin(ctx, ctx->prof_ks, s, e0, e1);
+    CHK(gemm_ks_launch(k, s));
+    if (ctx->prof_on) prof_end(ctx->prof_ks, s, e0, e1, 2.0 * p.M * (double)p.N * p.K);
+    return 0;
+  }
   if (xs_eligible(ctx, p)) {
     GemmXsParams x{p.A, p.lda, p.xs_pack, p.bias, p.col_scale, p.xs_scale_cols, p.act, p.M, p.N, p.n_split, p.out16, p.ld16, p.outT16, p.ldT16,
                    p.out32, p.ld32, p.res, p.ldres, 0};
@@ -112,7 +124,7 @@ int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p) {
 
 GemmParams lin_params(const half_t* A, int lda, int M, const Lin16& L) {
   GemmParams p = gemm_params_zero();
-  p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.K; p.M = M; p.N = L.N; p.K = L.K; p.bias = L.b; p.n_split = L.N; p.xs_pack = L.xs_pack;
+  p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.K; p.M = M; p.N = L.N; p.K = L.K; p.bias = L.b; p.n_split = L.N; p.xs_pack = L.xs_pack; p.ks_pack = L.ks_pack;
   return p;
 }
 
@@ -263,10 +275,12 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   if (ctx->cfg.feat_slots <= 0) ctx->cfg.feat_slots = 16;
   ctx->use_fused_mlp = getenv("SAM2MI_NO_FUSED_MLP") == nullptr;
   ctx->use_xs = getenv("SAM2MI_NO_XS") == nullptr;
+  ctx->use_ks = getenv("SAM2MI_KS") != nullptr;     // experimental (no end-to-end gain over the tiled kernel on fc2): opt-in
   hipError_t e = gemm_init();
   if (e == hipSuccess) e = flash256_init();
   if (e == hipSuccess) e = mlp_fused_init();
   if (e == hipSuccess) e = gemm_xs_init();
+  if (e == hipSuccess) e = gemm_ks_init();
   if (e != hipSuccess) {
     sam2mi_set_error(nullptr, "gemm_init", hipGetErrorString(e));
     delete ctx;
@@ -280,7 +294,7 @@ extern "C" void sam2mi_destroy(sam2mi_ctx* ctx) {
   if (!ctx) return;
   hipDeviceSynchronize();
   for (void* p : ctx->allocs) hipFree(p);
-  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp, &ctx->prof_xs}) {
+  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp, &ctx->prof_xs, &ctx->prof_ks}) {
     for (auto& pr : a->pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto& pr : a->pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
   }
@@ -306,14 +320,14 @@ extern "C" int sam2mi_load_weight(sam2mi_ctx* ctx, const char* key, const float*
 extern "C" int sam2mi_profile_enable(sam2mi_ctx* ctx, int on) {
   ctx->prof_on = on != 0;
   if (on) {
-    for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp, &ctx->prof_xs}) { a->ms = 0; a->flops = 0; a->launches = 0; }
+    for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp, &ctx->prof_xs, &ctx->prof_ks}) { a->ms = 0; a->flops = 0; a->launches = 0; }
   }
   return 0;
 }
 
 extern "C" int sam2mi_profile_read(sam2mi_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches,
                                    double* attn_ms, double* attn_flops, int64_t* attn_launches) {
-  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp, &ctx->prof_xs}) {
+  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp, &ctx->prof_xs, &ctx->prof_ks}) {
     for (auto& pr : a->pending) {
       hipEventSynchronize(pr.second);
       float ms = 0;
@@ -335,6 +349,9 @@ extern "C" int sam2mi_profile_read(sam2mi_ctx* ctx, double* gemm_ms, double* gem
 static int prof_read_one(ProfAcc& a, double* ms, double* flops, int64_t* launches);
 extern "C" int sam2mi_profile_read_xs(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* launches) {
   return ctx ? prof_read_one(ctx->prof_xs, ms, flops, launches) : 1;
+}
+extern "C" int sam2mi_profile_read_ks(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* launches) {
+  return ctx ? prof_read_one(ctx->prof_ks, ms, flops, launches) : 1;
 }
 extern "C" int sam2mi_profile_read_mlp(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* launches) {
   return ctx ? prof_read_one(ctx->prof_mlp, ms, flops, launches) : 1;
@@ -404,6 +421,11 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
         if (!pk.ok || !L->w || !gemm_xs_supported(L->N, L->K) || (L == &b.fc1 && mlp_fused_supported(b.dim_out))) continue;
         L->xs_pack = (half_t*)dalloc(ctx, gemm_xs_pack_bytes(L->N, L->K));
         if (!L->xs_pack || gemm_xs_pack(L->w, L->N, L->K, L->K, L->xs_pack, nullptr) != hipSuccess) pk.ok = false;
+      }
+      for (Lin16* L : {&b.fc2}) {       // stage 3 (N = 576, K = 2304): fc2 in the accumulator-stationary kernel's order (the projection, K = 576, is faster tiled)
+        if (!pk.ok || !L->w || !gemm_ks_supported(L->N, L->K)) continue;
+        L->ks_pack = (half_t*)dalloc(ctx, gemm_ks_pack_bytes(L->N, L->K));
+        if (!L->ks_pack || gemm_ks_pack(L->w, L->N, L->K, L->K, L->ks_pack, nullptr) != hipSuccess) pk.ok = false;
       }
       if (pk.ok && mlp_fused_supported(b.dim_out)) {     // stages 1-2: weights also in the fused MLP kernel's piece order
         b.mlp_pack = (half_t*)dalloc(ctx, mlp_fused_pack_bytes(b.dim_out));

@@ -40,6 +40,16 @@ extern "C" int sam2mi_debug_gemm(sam2mi_ctx* ctx, void* stream, const float* A, 
   p.A = a16; p.lda = K; p.W = w16; p.ldw = K; p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act & 0xFF; p.n_split = N;
   p.tile_hint = act >> 8;            // tests: force a tile / kernel variant
   p.res = residual; p.ldres = N; p.out32 = out; p.ld32 = N;
+  if (p.tile_hint == 31) {               // accumulator-stationary kernel (N = 576, K % 64 == 0)
+    if (!gemm_ks_supported(N, K) || (act & 0xFF)) return sam2mi_set_error(ctx, __func__, "gemm_ks needs N == 576, K % 64 == 0, no activation");
+    half_t* wp = t.get<half_t>(gemm_ks_pack_bytes(N, K) / 2);
+    if (!wp) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+    CHK(gemm_ks_pack(w16, N, K, K, wp, s));
+    GemmKsParams k{a16, K, wp, bias, residual, N, out, N, M, K};
+    CHK(gemm_ks_launch(k, s));
+    CHK(hipStreamSynchronize(s));
+    return 0;
+  }
   if (p.tile_hint == 30) {               // X-stationary kernel (K = 144 / 288 / 576): pack W, then the production dispatch path
     if (!gemm_xs_supported(N, K)) return sam2mi_set_error(ctx, __func__, "gemm_xs needs K in {144,288,576}, N % 8 == 0");
     half_t* wp = t.get<half_t>(gemm_xs_pack_bytes(N, K) / 2);
@@ -245,7 +255,19 @@ extern "C" int sam2mi_debug_gemm_bench(sam2mi_ctx* ctx, void* stream, int M, int
     CHK(gemm_xs_pack(w16, N, K, K, wpk, s));
     xsp = GemmXsParams{a16, K, wpk, bz, nullptr, 0, p.act, M, N, N, p.out16, p.ld16, nullptr, 0, p.out32, p.ld32, p.res, p.ldres, 0};
   }
-  auto launch = [&]() -> hipError_t { return tile_hint == 30 ? gemm_xs_launch(xsp, K, s) : gemm_launch(p, s); };
+  GemmKsParams ksp{};
+  if (tile_hint == 31) {
+    if (!gemm_ks_supported(N, K) || mode != 1) return sam2mi_set_error(ctx, __func__, "gemm_ks needs N == 576, K % 64 == 0, mode 1");
+    wpk = t.get<half_t>(gemm_ks_pack_bytes(N, K) / 2);
+    float* bz = t.get<float>((size_t)N);
+    if (!wpk || !bz) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+    CHK(hipMemsetAsync(bz, 0, (size_t)N * sizeof(float), s));
+    CHK(gemm_ks_pack(w16, N, K, K, wpk, s));
+    ksp = GemmKsParams{a16, K, wpk, bz, o32, N, o32, N, M, K};
+  }
+  auto launch = [&]() -> hipError_t {
+    return tile_hint == 30 ? gemm_xs_launch(xsp, K, s) : (tile_hint == 31 ? gemm_ks_launch(ksp, s) : gemm_launch(p, s));
+  };
   for (int i = 0; i < 3; ++i) CHK(launch());
   hipEvent_t e0, e1;
   CHK(hipEventCreate(&e0));

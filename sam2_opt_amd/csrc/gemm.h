@@ -26,6 +26,7 @@ struct GemmParams {
   int rope_len, rope_rows, rope_cols, rope_dim;
   int tile_hint;                 // 0 = automatic tile choice; 1..5 force a v2 tile (benchmarks)
   const half_t* xs_pack;         // W in the piece order of the X-stationary kernel (gemm_xs.hip), or null
+  const half_t* ks_pack;         // W in the piece order of the accumulator-stationary kernel (gemm_ks.hip: N = 576), or null
   int xs_scale_cols;             // col_scale is 1 from this column on (lets the X-stationary kernel keep only the q scale); 0: unknown
 };
 

@@ -19,7 +19,7 @@ EXPORTS = [
     "sam2mi_finalize_weights", "sam2mi_image_encoder", "sam2mi_set_image_e2e", "sam2mi_memory_attention",
     "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_dense_pe", "sam2mi_video_encode", "sam2mi_video_encode_u8", "sam2mi_fill_holes", "sam2mi_set_fill_hole_area",
     "sam2mi_video_click", "sam2mi_video_mask", "sam2mi_image_predict", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_video_track_batch", "sam2mi_resize_bilinear",
-    "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_profile_read_mlp", "sam2mi_profile_read_xs", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
+    "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_profile_read_mlp", "sam2mi_profile_read_xs", "sam2mi_profile_read_ks", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
     "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench", "sam2mi_debug_mlp",
 ]
 
@@ -328,7 +328,13 @@ class Engine:
         self._check(self.lib.sam2mi_profile_read_xs(self.h, *[C.byref(y) for y in x]), "sam2mi_profile_read_xs")
         return dict(gemm_ms=v[0].value, gemm_flops=v[1].value, gemm_launches=v[2].value, attn_ms=v[3].value,
                     attn_flops=v[4].value, attn_launches=v[5].value, mlp_ms=m[0].value, mlp_flops=m[1].value,
-                    mlp_launches=m[2].value, xs_ms=x[0].value, xs_flops=x[1].value, xs_launches=x[2].value)
+                    mlp_launches=m[2].value, xs_ms=x[0].value, xs_flops=x[1].value, xs_launches=x[2].value, **self._prof3("ks"))
+
+    def _prof3(self, name):
+        v = [C.c_double(), C.c_double(), C.c_int64()]
+        fn = getattr(self.lib, f"sam2mi_profile_read_{name}")
+        self._check(fn(self.h, *[C.byref(y) for y in v]), f"sam2mi_profile_read_{name}")
+        return {f"{name}_ms": v[0].value, f"{name}_flops": v[1].value, f"{name}_launches": v[2].value}
 
     # ------------------------------------------------------------------ single-kernel debug entry points (tests)
     def debug_gemm(self, A, W, bias=None, act=0, residual=None, tile_hint=0):

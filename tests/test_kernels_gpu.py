@@ -132,3 +132,20 @@ def test_gemm_xs(eng, M, N, K, act, res):
     if res:
         ref = ref + R.double()
     check(f"gemm_xs {M}x{N}x{K} act{act}", out, ref.float(), 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("M,K,res", [(4096, 2304, True), (1000, 576, True), (128, 128, False), (333, 1152, False)])
+def test_gemm_ks(eng, M, K, res):
+    """Accumulator-stationary N = 576 GEMM (gemm_ks.hip; projection / fc2 of Hiera stage 3) vs fp64 PyTorch on f16-rounded
+    operands: f32 output with bias and optional residual, ragged M."""
+    N = 576
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + K)
+    A = r16(torch.randn(M, K, generator=g)).cuda()
+    W = r16(torch.randn(N, K, generator=g) / math.sqrt(K)).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    R = torch.randn(M, N, generator=g).cuda() if res else None
+    out = eng.debug_gemm(A, W, b, 0, R, tile_hint=31)
+    ref = A.double() @ W.double().t() + b.double()
+    if res:
+        ref = ref + R.double()
+    check(f"gemm_ks {M}x{N}x{K}", out, ref.float(), 1e-4, 1e-5)

@@ -36,15 +36,19 @@ def main():
     print("|---|---|---|---|---|---|")
     for tot, k, n, f, w in rows[:16]:
         print(f"| `{k[:70]}` | {n} | {f:.2f} | {2 * f:.2f} | {w:.2f} | {tot / n * 1e3:.1f} |")
-    gem = [(tot, k, n, f, w) for tot, k, n, f, w in rows if "gemm_v2_kernel" in k]
-    if gem and len(sys.argv) > 4:
+    out = {}
+    for fam in ("gemm_v2_kernel", "gemm_xs_kernel", "mlp_fused_kernel"):
+        gem = [(tot, k, n, f, w) for tot, k, n, f, w in rows if fam in k]
+        if not gem:
+            continue
         tot = sum(g[0] for g in gem)
         n = sum(g[2] for g in gem)
-        out = {"gemm_v2_kernel": {"bytes_per_launch": round(tot * 1e9 / n, -5), "launches": n,
-                                  "fetch_x2_gb": round(sum(2 * g[3] for g in gem), 2), "write_gb": round(sum(g[4] for g in gem), 2),
-                                  "source": label + " (all gemm_v2_kernel tile instantiations)"}}
+        out[fam] = {"bytes_per_launch": round(tot * 1e9 / n, -5), "launches": n,
+                    "fetch_x2_gb": round(sum(2 * g[3] for g in gem), 2), "write_gb": round(sum(g[4] for g in gem), 2),
+                    "source": label + f" (all {fam} instantiations)"}
+        print(f"\n{fam} (all instantiations): {n} launches, {tot:.1f} GB = {tot / n * 1e3:.1f} MB per launch")
+    if out and len(sys.argv) > 4:
         json.dump(out, open(sys.argv[4], "w"), indent=1)
-        print(f"\ngemm_v2_kernel (all tiles): {n} launches, {tot:.1f} GB = {tot / n * 1e3:.1f} MB per launch")
 
 
 if __name__ == "__main__":
