@@ -17,6 +17,7 @@
 // Grid = (M / 128 token blocks) x (column splits): the column range is split so that the chip holds two waves per SIMD.
 #include "gemm_xs.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -30,18 +31,21 @@ static __device__ __forceinline__ const char* sgpr_ptr(const char* p) {
   return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
 
-constexpr int NW = 4;                    // waves per workgroup (two workgroups per CU)
-constexpr int STAGE_PIECES = 36;         // 1-KiB pieces per ring stage (9 per wave)
-constexpr int STAGE_B = STAGE_PIECES * 1024;
-constexpr int NST = 2;
+constexpr int NW = 8;                    // waves per workgroup = 8 token blocks of 32 (one workgroup per CU, two waves per SIMD)
+constexpr int STAGE_PIECES = 36;         // 1-KiB fragment pieces per ring stage ...
+constexpr int PPW = (STAGE_PIECES + NW - 1) / NW;     // ... 5 per wave: the packed image pads every stage with 4 zero pieces
+constexpr int STAGE_SLOTS = PPW * NW;    // 40
+constexpr int STAGE_B = STAGE_SLOTS * 1024;
+constexpr int NST = 3;                   // two stages in flight while one is consumed
 constexpr int MAX_COLS = 1152;           // output columns per workgroup (bias table in LDS)
 constexpr int MAX_SCALE = 576;           // of which at most this many leading ones carry a column scale
-constexpr int LDS_B = NST * STAGE_B + (MAX_COLS + MAX_SCALE) * 4;       // 80,640 B: two workgroups per CU
+constexpr int LDS_B = NST * STAGE_B + (MAX_COLS + MAX_SCALE) * 4;       // 129,792 B
 template <int K> constexpr int frag_batch() { return K == 144 ? 5 : 6; }   // fragments per LDS read batch (double-buffered)
 
 // GELU: erf-GELU on the row-major columns; F32: f32 output (+ residual) instead of f16 for the row-major columns
-template <int K, bool GELU, bool F32>
-__global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmXsParams p) {
+// ABL != 0: timing ablations (wrong results; tuning aid): 1 no LDS-DMA in the loop, 2 no MFMA, 3 no output stores
+template <int K, bool GELU, bool F32, int ABL = 0>
+__global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams p) {
   constexpr int KS = K / 16;             // k-steps = pieces per chunk
   constexpr int CPS = STAGE_PIECES / KS; // chunks (of 32 output columns) per stage
   constexpr int FB = frag_batch<K>();
@@ -69,16 +73,18 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmXsParams p) {
   float* bias_lds = reinterpret_cast<float*>(smem + NST * STAGE_B);
   float* scale_lds = bias_lds + MAX_COLS;
   const int col_lo = st_lo * CPS * 32, col_hi = min(p.N, st_hi * CPS * 32);
-  for (int i = tid; i < MAX_COLS; i += 256) bias_lds[i] = (col_lo + i < col_hi) ? p.bias[col_lo + i] : 0.f;
-  for (int i = tid; i < MAX_SCALE; i += 256) scale_lds[i] = (p.col_scale && col_lo + i < p.scale_cols) ? p.col_scale[col_lo + i] : 1.f;
+  for (int i = tid; i < MAX_COLS; i += 64 * NW) bias_lds[i] = (col_lo + i < col_hi) ? p.bias[col_lo + i] : 0.f;
+  for (int i = tid; i < MAX_SCALE; i += 64 * NW) scale_lds[i] = (p.col_scale && col_lo + i < p.scale_cols) ? p.col_scale[col_lo + i] : 1.f;
   __syncthreads();
   const char* wp = reinterpret_cast<const char*>(p.wpack);
   const unsigned lane_off = (unsigned)lane * 16u;
-  auto issue = [&](int st) {             // stage st -> ring slot (st - st_lo) % NST
+  // ring step st loads stage min(st, st_hi-1) into slot (st - st_lo) % NST (past the end: the last stage again, into a slot
+  // nobody reads), so every wave issues exactly PPW pieces per iteration and the vmcnt waits can be counted
+  auto issue = [&](int st) {
     char* sb = smem + ((st - st_lo) % NST) * STAGE_B;
-    const char* cb = wp + (size_t)st * STAGE_B;
+    const char* cb = wp + (size_t)min(st, st_hi - 1) * STAGE_B;
 #pragma unroll
-    for (int k = 0; k < STAGE_PIECES / NW; ++k) {
+    for (int k = 0; k < PPW; ++k) {
       const int q = wave + NW * k;
       const char* src = sgpr_ptr(cb + q * 1024);
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + lane_off), (lds_ptr_t)(sb + q * 1024), 16, 0, 0);
@@ -106,7 +112,10 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmXsParams p) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < FB; ++j)
-        if (b * FB + j < KS) sa = SWAP ? mfma32(xf[b * FB + j], cur[j], sa) : mfma32(cur[j], xf[b * FB + j], sa);
+        if (b * FB + j < KS) {
+          if (ABL != 2) sa = SWAP ? mfma32(xf[b * FB + j], cur[j], sa) : mfma32(cur[j], xf[b * FB + j], sa);
+          else asm volatile("" ::"v"(cur[j]), "v"(xf[b * FB + j]));
+        }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < FB; ++j) cur[j] = nxt[j];
@@ -134,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmXsParams p) {
       for (int e = 0; e < 4; ++e) { v[e] *= c0[e]; v[4 + e] *= c1[e]; v[8 + e] *= c2[e]; v[12 + e] *= c3[e]; }
     }
     const int tok = tok0 + fr;
+    if (ABL == 3) { asm volatile("" ::"v"(v[0]), "v"(v[15])); return; }
     if (tok < p.M) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -185,16 +195,19 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmXsParams p) {
   };
 
   issue(st_lo);
+  issue(st_lo + 1);
 #pragma nounroll
   for (int st = st_lo; st < st_hi; ++st) {
-    // Stage st landed.  Its 9 pieces were the first vector-memory operations of the previous iteration; behind them every
-    // chunk issued at least 2 more (2 f16 stores, or 4 transposed stores, or 4 residual loads + 4 f32 stores).  vmcnt retires
-    // in order, so leaving the 2 youngest per chunk outstanding never skips a piece and does not wait for the last store
-    // acknowledgements.  Ragged M: some waves store nothing -> drain.
-    if (st == st_lo || (p.M & 127)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first stage: nothing was issued behind its pieces
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CPS) : "memory");
-    __builtin_amdgcn_s_barrier();                         // ... for every wave; everyone is done with the other slot
-    if (st + 1 < st_hi) issue(st + 1);
+    // Stage st landed; stage st+1 stays in flight.  Vector-memory order of a wave (old -> young):
+    //   pieces(st) | stores(st-2) | pieces(st+1) | stores(st-1)          (5 pieces per stage; >= 2 stores per chunk)
+    // vmcnt retires in order, so with N outstanding allowed, N <= (operations younger than pieces(st)) keeps every piece of
+    // stage st complete: 5 in the first iteration, 5 + 2 CPS in the second, 5 + 4 CPS afterwards - without waiting for the
+    // store acknowledgements.  M % 256 != 0: some waves store nothing -> 5.
+    if (st == st_lo || (p.M & (32 * NW - 1))) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else if (st == st_lo + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2 * CPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 4 * CPS) : "memory");
+    __builtin_amdgcn_s_barrier();                         // ... for every wave; everyone is past stage st-1 -> its slot is free
+    if (ABL != 1) issue(st + 2);
     const char* sb = smem + ((st - st_lo) % NST) * STAGE_B;
 #pragma unroll
     for (int c = 0; c < CPS; ++c) {
@@ -204,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void gemm_xs_kernel(const GemmXsParams p) {
       else chunk_trans(sb + c * KS * 1024 + rd_nat, n0);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing duplicate pieces land before the LDS is released
 }
 
 // one thread per 16-B unit of the packed image: stage = 36 pieces = CPS chunks x KS k-steps; piece (c, s) holds rows
@@ -213,15 +227,17 @@ __global__ void gemm_xs_pack_kernel(const half_t* __restrict__ w, int N, int ldw
   constexpr int KS = K / 16;
   const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= units) return;
-  const long piece = u >> 6;
+  const long slot = u >> 6;
   const int l = (int)(u & 63), row = l >> 1, h = (l & 1) ^ ((row >> 3) & 1);
-  const long chunk = piece / KS;
-  const int s = (int)(piece - chunk * KS);
+  const long stage = slot / STAGE_SLOTS;
+  const int q = (int)(slot - stage * STAGE_SLOTS);       // pieces 36..39 of a stage are zero padding
+  const long chunk = stage * (STAGE_PIECES / KS) + q / KS;
+  const int s = q % KS;
   const long n = chunk * 32 + row;
   half8 v;
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = (half_t)0.f;
-  if (n < N) v = *reinterpret_cast<const half8*>(w + n * ldw + 16 * s + 8 * h);
+  if (q < STAGE_PIECES && n < N) v = *reinterpret_cast<const half8*>(w + n * ldw + 16 * s + 8 * h);
   *reinterpret_cast<half8*>(out + u * 8) = v;
 }
 
@@ -231,7 +247,7 @@ hipError_t launch_k(const GemmXsParams& p, hipStream_t s) {
   const int nstages = (p.N + 32 * CPS - 1) / (32 * CPS);
   const int tb = (p.M + 32 * NW - 1) / (32 * NW);
   // column splits: fill the chip with two workgroups per CU (512 slots) at least once, never more splits than stages
-  int splits = (2 * 256 + tb - 1) / tb;
+  int splits = (256 + tb - 1) / tb;                                     // one workgroup (8 waves) per CU
   if (p.splits > 0) splits = p.splits;
   const int max_stages = MAX_COLS / (32 * CPS);                         // bias table: at most MAX_COLS columns per workgroup
   splits = std::max(splits, (nstages + max_stages - 1) / max_stages);
@@ -241,7 +257,13 @@ hipError_t launch_k(const GemmXsParams& p, hipStream_t s) {
   if (p.out32 && p.act == ACT_GELU) gemm_xs_kernel<K, true, true><<<grid, block, LDS_B, s>>>(p);      // tests only
   else if (p.out32) gemm_xs_kernel<K, false, true><<<grid, block, LDS_B, s>>>(p);
   else if (p.act == ACT_GELU) gemm_xs_kernel<K, true, false><<<grid, block, LDS_B, s>>>(p);
-  else gemm_xs_kernel<K, false, false><<<grid, block, LDS_B, s>>>(p);
+  else {
+    static const int abl = getenv("SAM2MI_XS_ABL") ? atoi(getenv("SAM2MI_XS_ABL")) : 0;      // tuning aid (f16 / no-GELU variant only)
+    if (abl == 1) gemm_xs_kernel<K, false, false, 1><<<grid, block, LDS_B, s>>>(p);
+    else if (abl == 2) gemm_xs_kernel<K, false, false, 2><<<grid, block, LDS_B, s>>>(p);
+    else if (abl == 3) gemm_xs_kernel<K, false, false, 3><<<grid, block, LDS_B, s>>>(p);
+    else gemm_xs_kernel<K, false, false><<<grid, block, LDS_B, s>>>(p);
+  }
   return hipGetLastError();
 }
 template <int K>
@@ -250,6 +272,9 @@ hipError_t attr_k() {
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, false, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
   return e;
 }
 }  // namespace
