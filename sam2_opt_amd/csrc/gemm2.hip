@@ -16,6 +16,7 @@
 //     itself has one column per lane); transposed outputs are stored straight from the accumulators
 //     (4 consecutive rows per lane).
 #include "gemm.h"
+#include <cstdlib>
 
 #ifndef KUNROLL
 #define KUNROLL 4
@@ -314,10 +315,10 @@ hipError_t v2_attr() {
 }  // namespace
 
 hipError_t gemm_v2_init() {
-  hipError_t e[13] = {v2_attr<256, 256, 4, 4, 2>(), v2_attr<256, 192, 4, 3, 2>(), v2_attr<256, 128, 4, 2, 3>(), v2_attr<128, 128, 2, 2, 2>(), v2_attr<128, 64, 2, 2, 2>(), v2_attr<64, 64, 2, 2, 2>(),
+  hipError_t e[15] = {v2_attr<128, 192, 4, 2, 2>(), v2_attr<256, 192, 4, 2, 2>(), v2_attr<256, 256, 4, 4, 2>(), v2_attr<256, 192, 4, 3, 2>(), v2_attr<256, 128, 4, 2, 3>(), v2_attr<128, 128, 2, 2, 2>(), v2_attr<128, 64, 2, 2, 2>(), v2_attr<64, 64, 2, 2, 2>(),
                       v2_attr<128, 64, 2, 2, 3>(), v2_attr<128, 128, 2, 2, 3>(), v2_attr<64, 64, 2, 2, 4>(),
                       v2_attr<128, 128, 4, 2, 2>(), v2_attr<256, 128, 4, 2, 2>(), v2_attr<256, 64, 4, 2, 2>(), v2_attr<128, 64, 4, 2, 2>()};
-  for (int i = 0; i < 13; ++i)
+  for (int i = 0; i < 15; ++i)
     if (e[i] != hipSuccess) return e[i];
   return hipSuccess;
 }
@@ -346,10 +347,16 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   if (force == 11) return v2_launch<256, 128, 4, 2, 2>(p, s);
   if (force == 12) return v2_launch<256, 64, 4, 2, 2>(p, s);
   if (force == 13) return v2_launch<128, 64, 4, 2, 2>(p, s);
+  if (force == 16) return v2_launch<128, 192, 4, 2, 2>(p, s);
+  if (force == 17) return v2_launch<256, 192, 4, 2, 2>(p, s);
   if (force == 14) return v2_launch<256, 256, 4, 4, 2>(p, s);
   if (force == 15) return v2_launch<256, 192, 4, 3, 2>(p, s);
   if (force == 4) return v2_launch<128, 64, 2, 2, 2>(p, s);
   if (force == 5) return v2_launch<64, 64, 2, 2, 2>(p, s);
+  // long K, N a multiple of 192 (fc2 of stages 3-4: N = 576 / 1152): the 128x192 tile re-reads the A panel N/192 instead of
+  // N/64 times through the L2->LDS path that bounds this kernel (measured +14 % / +16 % on those two shapes)
+  static const bool no_t192 = getenv("SAM2MI_NO_T192") != nullptr;      // A/B aid
+  if (!no_t192 && p.N % 192 == 0 && p.K >= 2048 && p.M >= 4096) return v2_launch<128, 192, 4, 2, 2>(p, s);
   const int n128 = ((p.N + 127) / 128) * 128;
   const long t128 = tiles_of(p, 128, 128);
   const bool fits128 = (n128 - p.N) * 100 <= 8 * p.N;              // N pads to 128 with at most 8 % waste

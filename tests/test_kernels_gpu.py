@@ -27,7 +27,7 @@ def r16(x):
     (300, 200, 144, 0, False), (4096, 1728, 576, 0, False), (16384, 432, 144, 1, True), (8, 256, 256, 2, False),
     (1000, 64, 160, 0, True), (4096, 4, 32, 0, False), (129, 65, 2304, 1, True), (4096, 576, 2304, 0, True),
 ])
-@pytest.mark.parametrize("hint", [0, 2, 5, 6, 10, 13, 14, 15, 20])   # automatic (14: 16-wave 256x256, 15: 12-wave 256x192), 256x128, 64x64, persistent v3, 8-wave 128x128 / 128x64, 256x256 staggered (K % 64 == 0)
+@pytest.mark.parametrize("hint", [0, 2, 5, 6, 10, 13, 14, 15, 16, 20])   # automatic (14: 16-wave 256x256, 15: 12-wave 256x192, 16: 128x192), 256x128, 64x64, persistent v3, 8-wave 128x128 / 128x64, 256x256 staggered (K % 64 == 0)
 def test_gemm(eng, M, N, K, act, res, hint):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
     A = r16(torch.randn(M, K, generator=g)).cuda()
