@@ -84,6 +84,13 @@ def main():
     state = pred.init_state(frames=frames, video_height=1024, video_width=1024)       # frames resident in HBM from here on
     pred.add_new_points_or_box(state, 0, 1, points=np.array([[512.0, 512.0]], np.float32), labels=np.array([1], np.int32))
 
+    # optional: drive the tracking path from a high-priority stream (the caller's current stream is what the predictor
+    # launches on, like the reference); tuning knob, off by default
+    if os.environ.get("SAM2MI_TRACK_PRIORITY"):
+        hp = torch.cuda.Stream(device=device, priority=int(os.environ["SAM2MI_TRACK_PRIORITY"]))
+        hp.wait_stream(torch.cuda.current_stream(device))
+        torch.cuda.set_stream(hp)
+
     def one_step():
         n, chk = 0, None
         for _, _, masks in pred.propagate_in_video(state):

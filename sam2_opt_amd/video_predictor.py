@@ -53,7 +53,9 @@ class SAM2VideoPredictor:
         # leaves most CUs idle, the encoder fills them.  The two paths share no workspace inside the engine.
         self.object_batch = 8                       # objects per batched tracking pass (1: loop objects like the reference)
         self.overlap_encode = bool(overlap_encode)
-        self._enc_stream = torch.cuda.Stream(device=self.device) if self.overlap_encode else None
+        import os as _os
+        _prio = int(_os.environ.get("SAM2MI_ENC_PRIORITY", "0"))      # tuning: -1 = high-priority encoder stream
+        self._enc_stream = torch.cuda.Stream(device=self.device, priority=_prio) if self.overlap_encode else None
         self.backend = "hip"
         self.debug_trace = None      # set to {} to record per-frame intermediates (parity tests)
 
