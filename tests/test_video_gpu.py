@@ -2,8 +2,8 @@
  (a) golden vectors recorded from the REAL reference's propagate_in_video (tests/golden/large_video24.npz), and
  (b) the CPU oracle's per-frame intermediates on the first frames.
 Tolerances (f16 MFMA operands, f32 accumulate; the memory bank is bf16-rounded as in the reference):
-mask logits max-abs error <= 5e-3 * max|ref| and relative L2 <= 5e-3 per frame, binarised-pixel
-disagreement <= 2e-3 (measured: 1.9e-3 / 2.0e-3 / 1.0e-3)."""
+mask logits max-abs error <= 3e-3 * max|ref| and relative L2 <= 3e-3 per frame, binarised-pixel
+disagreement <= 1.5e-3 (measured: 2.2e-3 / 2.0e-3 / 1.0e-3)."""
 import numpy as np
 import pytest
 import torch
@@ -49,7 +49,7 @@ def test_video_matches_reference_golden(predictor, cfg_large, golden_video):
         n += 1
     assert n == T
     print(f"[parity] video worst over {T} frames: {worst}", flush=True)
-    assert worst["max_rel"] <= 5e-3 and worst["l2"] <= 5e-3 and worst["dis"] <= 2e-3, worst
+    assert worst["max_rel"] <= 3e-3 and worst["l2"] <= 3e-3 and worst["dis"] <= 1.5e-3, worst
 
 
 def test_video_intermediates_match_oracle(predictor, sd_large, cfg_large):
