@@ -23,6 +23,19 @@ def _newer(a, b):
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Build (or reuse) the in-tree library.  Serialised across processes with a file lock: the ranks of a multi-GPU
+    launch call this concurrently and must not compile into the same object files at once."""
+    import fcntl
+    os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
