@@ -1,7 +1,4 @@
 #!/bin/bash
-# A/B of two-stream overlap knobs on one box (frames/s of the default bench, 3 steps each)
+# A/B of tuning knobs on one box (frames/s of the default bench, 3 steps each)
 run() { echo -n "$1: "; env $1 python bench.py --steps 3 --no-cpu-baseline --no-roofline 2>&1 | tail -n 1 | python -c "import json,sys; print(json.loads(sys.stdin.read())['value'])"; }
-run "X=0"
-run "SAM2MI_TRACK_PRIORITY=-1"
-run "SAM2MI_TRACK_PRIORITY=-1 SAM2MI_FLASH_STAGES=3"
-run "X=0"
+for k in "$@"; do run "$k"; done
