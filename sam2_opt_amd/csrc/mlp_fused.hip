@@ -11,14 +11,15 @@
 //     "V^T" = W2 chunk [C out channels, 32 hidden units]  ->  Y^T += W2_chunk . P           (C/32 tiles x 2 k-steps)
 // W1 rows are read PERMUTED (hidden unit pi23(i) on MFMA row i, bits 2 and 3 swapped) so that the accumulator registers a
 // lane owns are exactly hidden units 16 ks + 8 fh + 0..7 in B-operand order (same trick as flash256_v3, attn_flash256.hip).
-// Weights travel through an LDS ring by LDS-DMA in 1-KiB pieces that ARE fragment tiles (32 rows x 32 B): the per-lane
-// source offset is one constant per operand, the piece base is wave-uniform, and a fragment read is
-// stage + piece * 1024 + lane constant (immediate offsets).  The two 16-B halves of a row are swapped on rows with bit 3
-// set (on the DMA source address), which makes every 16-lane ds_read_b128 group conflict-free.
+// Weights travel through a 4-slot LDS ring by LDS-DMA in 1-KiB pieces that ARE fragment tiles (32 rows x 32 B), from an image
+// PACKED at weight-load time in exactly that order (mlp_fused_pack): every piece is 8 full cache lines, its source is
+// wave-uniform base + 16 * lane, and a fragment read is slot + piece * 1024 + lane constant (immediate offsets).  The two
+// 16-B halves of a row are swapped on rows with bit 3 set (in the packed image), which makes every 16-lane ds_read_b128
+// group conflict-free.
 // One workgroup = 4 waves (one per SIMD, up to 512 registers) = 128 * TN tokens; all workgroups stream the same weights
 // (L2 resident): L2->LDS traffic per token is 16 C^2 / (128 TN) bytes instead of 2 x (A + W tiles) per 128x128 GEMM tile.
-// b1 is the initial value of the S^T accumulator; b2 and the f32 residual are added when Y^T is written back (16-B
-// stores: 4 consecutive channels per lane).
+// b1 is added in front of the GELU (LDS table); b2 and the f32 residual are added when Y^T is written back (16-B stores:
+// 4 consecutive channels per lane).  The chunk loop is software-pipelined (see mlp_fused_kernel).
 #include "mlp_fused.h"
 #include <cstdlib>
 
