@@ -199,6 +199,10 @@ int sam2mi_profile_read_xs(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* 
 /* Same for the accumulator-stationary N = 576 GEMM (gemm_ks_kernel: projection / fc2 of Hiera stage 3). */
 int sam2mi_profile_read_ks(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* launches);
 
+/* The GEMM-family launches again, per kernel instantiation: one line "name\tms\tflops\tlaunches\n" each, names as rocprofv3
+ * prints them (e.g. "gemm_xs_kernel<576, true, false, 0>").  Returns the bytes written (NUL-terminated), -1 if cap is too small. */
+int sam2mi_profile_read_kernels(sam2mi_ctx* ctx, char* out, int cap);
+
 /* Debug/test entry points: single kernels behind the C ABI (used by tests/test_kernels_gpu.py). */
 int sam2mi_debug_gemm(sam2mi_ctx* ctx, void* stream, const float* A, const float* W, const float* bias, int M, int N, int K,
                       int act, const float* residual, float* out);

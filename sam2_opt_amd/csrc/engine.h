@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -68,7 +69,8 @@ struct DecLayerW {
 struct ProfAcc {
   double ms = 0, flops = 0;
   int64_t launches = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  struct Pending { hipEvent_t first, second; ProfAcc* named; };   // named: the per-instantiation accumulator fed by the same events
+  std::vector<Pending> pending;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
 
@@ -181,6 +183,7 @@ struct sam2mi_ctx {
   // ---- profiling
   bool prof_on = false;
   ProfAcc prof_gemm, prof_attn, prof_mlp, prof_xs, prof_ks;
+  std::map<std::string, ProfAcc> prof_by_kernel;   // the GEMM-family launches again, keyed by kernel instantiation (rocprofv3 names)
   bool use_ks = false;             // accumulator-stationary GEMM for stage-3 fc2 (experimental, SAM2MI_KS=1; parity-tested, not faster end to end)
   bool use_xs = true;              // X-stationary GEMM for K <= 576 linears of the encoder (SAM2MI_NO_XS=1: tiled kernel)
   bool use_fused_mlp = true;       // stages with C <= 288: one fused fc1-GELU-fc2 kernel (SAM2MI_NO_FUSED_MLP=1: two GEMMs, for A/B runs)

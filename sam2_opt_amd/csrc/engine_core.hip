@@ -1,5 +1,6 @@
 // Context, weight packing, input-independent tables and profiled launch wrappers.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -30,17 +31,21 @@ static T* dupload(sam2mi_ctx* ctx, const std::vector<T>& v) {
 }
 
 // ------------------------------------------------------------------ profiling wrappers
+static void prof_drain(ProfAcc& a) {          // synchronises; profiling mode only
+  for (auto& pr : a.pending) {
+    hipEventSynchronize(pr.second);
+    float ms = 0;
+    hipEventElapsedTime(&ms, pr.first, pr.second);
+    a.ms += ms;
+    if (pr.named) pr.named->ms += ms;
+    a.pool.push_back({pr.first, pr.second});
+  }
+  a.pending.clear();
+}
 static void prof_begin(sam2mi_ctx* ctx, ProfAcc& a, hipStream_t s, hipEvent_t& e0, hipEvent_t& e1) {
   if (a.pool.empty()) {
     // drain pending (synchronises; profiling mode only)
-    for (auto& pr : a.pending) {
-      hipEventSynchronize(pr.second);
-      float ms = 0;
-      hipEventElapsedTime(&ms, pr.first, pr.second);
-      a.ms += ms;
-      a.pool.push_back(pr);
-    }
-    a.pending.clear();
+    prof_drain(a);
     if (a.pool.empty()) {
       for (int i = 0; i < 2048; ++i) {
         hipEvent_t x, y;
@@ -58,7 +63,18 @@ static void prof_begin(sam2mi_ctx* ctx, ProfAcc& a, hipStream_t s, hipEvent_t& e
 }
 static void prof_end(ProfAcc& a, hipStream_t s, hipEvent_t e0, hipEvent_t e1, double flops) {
   hipEventRecord(e1, s);
-  a.pending.push_back({e0, e1});
+  a.pending.push_back({e0, e1, nullptr});
+  a.flops += flops;
+  a.launches += 1;
+}
+
+// second accumulator keyed by the kernel instantiation: same events, drained together in sam2mi_profile_read_kernels
+static void prof_end_named(sam2mi_ctx* ctx, ProfAcc& a, const std::string& name, hipStream_t s, hipEvent_t e0, hipEvent_t e1, double flops) {
+  ProfAcc& k = ctx->prof_by_kernel[name];       // std::map: references stay valid
+  k.flops += flops;
+  k.launches += 1;
+  hipEventRecord(e1, s);
+  a.pending.push_back({e0, e1, &k});
   a.flops += flops;
   a.launches += 1;
 }
@@ -80,7 +96,7 @@ int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p) {
     hipEvent_t e0, e1;
     if (ctx->prof_on) prof_begin(ctx, ctx->prof_ks, s, e0, e1);
     CHK(gemm_ks_launch(k, s));
-    if (ctx->prof_on) prof_end(ctx->prof_ks, s, e0, e1, 2.0 * p.M * (double)p.N * p.K);
+    if (ctx->prof_on) prof_end_named(ctx, ctx->prof_ks, "gemm_ks_kernel<0>", s, e0, e1, 2.0 * p.M * (double)p.N * p.K);
     return 0;
   }
   if (xs_eligible(ctx, p)) {
@@ -89,20 +105,28 @@ int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p) {
     hipEvent_t e0, e1;
     if (ctx->prof_on) prof_begin(ctx, ctx->prof_xs, s, e0, e1);
     CHK(gemm_xs_launch(x, p.K, s));
-    if (ctx->prof_on) prof_end(ctx->prof_xs, s, e0, e1, 2.0 * p.M * (double)p.N * p.K);
+    if (ctx->prof_on) {
+      char nm[96];
+      snprintf(nm, sizeof(nm), "gemm_xs_kernel<%d, %s, %s, 0>", p.K, p.act == ACT_GELU ? "true" : "false", p.out32 ? "true" : "false");
+      prof_end_named(ctx, ctx->prof_xs, nm, s, e0, e1, 2.0 * p.M * (double)p.N * p.K);
+    }
     return 0;
   }
   hipEvent_t e0, e1;
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_gemm, s, e0, e1);
   CHK(gemm_launch(p, s));
-  if (ctx->prof_on) prof_end(ctx->prof_gemm, s, e0, e1, 2.0 * p.M * (double)p.N * p.K);
+  if (ctx->prof_on) prof_end_named(ctx, ctx->prof_gemm, gemm_v2_kernel_name(p), s, e0, e1, 2.0 * p.M * (double)p.N * p.K);
   return 0;
 }
 int run_mlp_fused(sam2mi_ctx* ctx, hipStream_t s, const MlpFusedParams& p, int C) {
   hipEvent_t e0, e1;
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_mlp, s, e0, e1);
   CHK(mlp_fused_launch(p, C, s));
-  if (ctx->prof_on) prof_end(ctx->prof_mlp, s, e0, e1, 2.0 * 2.0 * p.M * (double)C * (4.0 * C));   // fc1 + fc2
+  if (ctx->prof_on) {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "mlp_fused_kernel<%d, %d, 4>", C, C == 144 ? 2 : 1);
+    prof_end_named(ctx, ctx->prof_mlp, nm, s, e0, e1, 2.0 * 2.0 * p.M * (double)C * (4.0 * C));   // fc1 + fc2
+  }
   return 0;
 }
 int run_hiera_attn(sam2mi_ctx* ctx, hipStream_t s, const HieraAttnParams& p) {
@@ -321,6 +345,7 @@ extern "C" int sam2mi_profile_enable(sam2mi_ctx* ctx, int on) {
   ctx->prof_on = on != 0;
   if (on) {
     for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp, &ctx->prof_xs, &ctx->prof_ks}) { a->ms = 0; a->flops = 0; a->launches = 0; }
+    ctx->prof_by_kernel.clear();
   }
   return 0;
 }
@@ -328,14 +353,7 @@ extern "C" int sam2mi_profile_enable(sam2mi_ctx* ctx, int on) {
 extern "C" int sam2mi_profile_read(sam2mi_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches,
                                    double* attn_ms, double* attn_flops, int64_t* attn_launches) {
   for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp, &ctx->prof_xs, &ctx->prof_ks}) {
-    for (auto& pr : a->pending) {
-      hipEventSynchronize(pr.second);
-      float ms = 0;
-      hipEventElapsedTime(&ms, pr.first, pr.second);
-      a->ms += ms;
-      a->pool.push_back(pr);
-    }
-    a->pending.clear();
+    prof_drain(*a);
   }
   if (gemm_ms) *gemm_ms = ctx->prof_gemm.ms;
   if (gemm_flops) *gemm_flops = ctx->prof_gemm.flops;
@@ -347,6 +365,21 @@ extern "C" int sam2mi_profile_read(sam2mi_ctx* ctx, double* gemm_ms, double* gem
 }
 
 static int prof_read_one(ProfAcc& a, double* ms, double* flops, int64_t* launches);
+// One line per GEMM-family kernel instantiation: "name\tms\tflops\tlaunches\n" (names as rocprofv3 prints them).
+// Call after sam2mi_profile_read (which drains the events).  Returns the number of bytes written, or -1.
+extern "C" int sam2mi_profile_read_kernels(sam2mi_ctx* ctx, char* out, int cap) {
+  if (!ctx || !out || cap <= 0) return -1;
+  for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_mlp, &ctx->prof_xs, &ctx->prof_ks}) prof_drain(*a);
+  std::string sout;
+  for (auto& kv : ctx->prof_by_kernel) {
+    char line[256];
+    snprintf(line, sizeof(line), "%s\t%.6f\t%.6e\t%lld\n", kv.first.c_str(), kv.second.ms, kv.second.flops, (long long)kv.second.launches);
+    sout += line;
+  }
+  if ((int)sout.size() + 1 > cap) return -1;
+  memcpy(out, sout.c_str(), sout.size() + 1);
+  return (int)sout.size();
+}
 extern "C" int sam2mi_profile_read_xs(sam2mi_ctx* ctx, double* ms, double* flops, int64_t* launches) {
   return ctx ? prof_read_one(ctx->prof_xs, ms, flops, launches) : 1;
 }
@@ -357,14 +390,7 @@ extern "C" int sam2mi_profile_read_mlp(sam2mi_ctx* ctx, double* ms, double* flop
   return ctx ? prof_read_one(ctx->prof_mlp, ms, flops, launches) : 1;
 }
 static int prof_read_one(ProfAcc& a, double* ms, double* flops, int64_t* launches) {
-  for (auto& pr : a.pending) {
-    hipEventSynchronize(pr.second);
-    float t = 0;
-    hipEventElapsedTime(&t, pr.first, pr.second);
-    a.ms += t;
-    a.pool.push_back(pr);
-  }
-  a.pending.clear();
+  prof_drain(a);
   if (ms) *ms = a.ms;
   if (flops) *flops = a.flops;
   if (launches) *launches = a.launches;

@@ -42,6 +42,8 @@ hipError_t gemm_init();   // sets the dynamic-LDS attributes once
 // gemm2.hip: LDS-DMA pipelined kernel (K % 16 == 0); gemm_launch dispatches to it
 hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t stream);
 hipError_t gemm_v2_init();
+int gemm_v2_auto_tile(const GemmParams& p);              // the tile the automatic choice takes (0: 64x64 .. 3: 128x192)
+const char* gemm_v2_kernel_name(const GemmParams& p);    // kernel name as rocprofv3 prints it
 // gemm3.hip: persistent loader/consumer kernel (large M*N, K % 16 == 0)
 hipError_t gemm_v3_launch(const GemmParams& p, hipStream_t stream);
 hipError_t gemm_v3_init();

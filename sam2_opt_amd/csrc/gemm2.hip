@@ -353,14 +353,32 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   if (force == 15) return v2_launch<256, 192, 4, 3, 2>(p, s);
   if (force == 4) return v2_launch<128, 64, 2, 2, 2>(p, s);
   if (force == 5) return v2_launch<64, 64, 2, 2, 2>(p, s);
+  switch (gemm_v2_auto_tile(p)) {
+    case 3: return v2_launch<128, 192, 4, 2, 2>(p, s);
+    case 2: return v2_launch<128, 128, 4, 2, 2>(p, s);
+    case 1: return v2_launch<128, 64, 4, 2, 2>(p, s);
+    default: return v2_launch<64, 64, 2, 2, 2>(p, s);
+  }
+}
+
+// automatic tile: 3 = 128x192, 2 = 128x128, 1 = 128x64 (8 waves), 0 = 64x64 (4 waves)
+int gemm_v2_auto_tile(const GemmParams& p) {
   // long K, N a multiple of 192 (fc2 of stages 3-4: N = 576 / 1152): the 128x192 tile re-reads the A panel N/192 instead of
   // N/64 times through the L2->LDS path that bounds this kernel (measured +14 % / +16 % on those two shapes)
   static const bool no_t192 = getenv("SAM2MI_NO_T192") != nullptr;      // A/B aid
-  if (!no_t192 && p.N % 192 == 0 && p.K >= 2048 && p.M >= 4096) return v2_launch<128, 192, 4, 2, 2>(p, s);
+  if (!no_t192 && p.N % 192 == 0 && p.K >= 2048 && p.M >= 4096) return 3;
   const int n128 = ((p.N + 127) / 128) * 128;
   const long t128 = tiles_of(p, 128, 128);
   const bool fits128 = (n128 - p.N) * 100 <= 8 * p.N;              // N pads to 128 with at most 8 % waste
-  if (fits128 && (t128 >= 1536 || (t128 >= 512 && p.K >= 2048))) return v2_launch<128, 128, 4, 2, 2>(p, s);
-  if (tiles_of(p, 128, 64) >= 1024) return v2_launch<128, 64, 4, 2, 2>(p, s);
-  return v2_launch<64, 64, 2, 2, 2>(p, s);
+  if (fits128 && (t128 >= 1536 || (t128 >= 512 && p.K >= 2048))) return 2;
+  if (tiles_of(p, 128, 64) >= 1024) return 1;
+  return 0;
+}
+
+// kernel name as rocprofv3 prints it (profiling by instantiation)
+const char* gemm_v2_kernel_name(const GemmParams& p) {
+  if (p.tile_hint != 0) return "gemm_v2_kernel<forced tile>";
+  static const char* names[4] = {"gemm_v2_kernel<64, 64, 2, 2, 2>", "gemm_v2_kernel<128, 64, 4, 2, 2>", "gemm_v2_kernel<128, 128, 4, 2, 2>",
+                                 "gemm_v2_kernel<128, 192, 4, 2, 2>"};
+  return names[gemm_v2_auto_tile(p)];
 }

@@ -19,7 +19,7 @@ EXPORTS = [
     "sam2mi_finalize_weights", "sam2mi_image_encoder", "sam2mi_set_image_e2e", "sam2mi_memory_attention",
     "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_dense_pe", "sam2mi_video_encode", "sam2mi_video_encode_u8", "sam2mi_fill_holes", "sam2mi_set_fill_hole_area",
     "sam2mi_video_click", "sam2mi_video_mask", "sam2mi_image_predict", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_video_track_batch", "sam2mi_resize_bilinear",
-    "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_profile_read_mlp", "sam2mi_profile_read_xs", "sam2mi_profile_read_ks", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
+    "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_profile_read_mlp", "sam2mi_profile_read_xs", "sam2mi_profile_read_ks", "sam2mi_profile_read_kernels", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
     "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench", "sam2mi_debug_mlp",
 ]
 
@@ -329,6 +329,18 @@ class Engine:
         return dict(gemm_ms=v[0].value, gemm_flops=v[1].value, gemm_launches=v[2].value, attn_ms=v[3].value,
                     attn_flops=v[4].value, attn_launches=v[5].value, mlp_ms=m[0].value, mlp_flops=m[1].value,
                     mlp_launches=m[2].value, xs_ms=x[0].value, xs_flops=x[1].value, xs_launches=x[2].value, **self._prof3("ks"))
+
+    def profile_read_kernels(self) -> dict:
+        """{kernel instantiation name: dict(ms, flops, launches)} of the GEMM-family launches since profile_enable(True)."""
+        buf = C.create_string_buffer(1 << 16)
+        n = self.lib.sam2mi_profile_read_kernels(self.h, buf, len(buf))
+        if n < 0:
+            raise RuntimeError("sam2mi_profile_read_kernels failed")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, fl, cnt = line.split("\t")
+            out[name] = dict(ms=float(ms), flops=float(fl), launches=int(cnt))
+        return out
 
     def _prof3(self, name):
         v = [C.c_double(), C.c_double(), C.c_int64()]

@@ -47,6 +47,13 @@ def main():
                     "fetch_x2_gb": round(sum(2 * g[3] for g in gem), 2), "write_gb": round(sum(g[4] for g in gem), 2),
                     "source": label + f" (all {fam} instantiations)"}
         print(f"\n{fam} (all instantiations): {n} launches, {tot:.1f} GB = {tot / n * 1e3:.1f} MB per launch")
+    import re
+    inst = {}
+    for tot, k, n, f, w in rows:
+        m = re.search(r"(gemm_v2_kernel|gemm_xs_kernel|mlp_fused_kernel|gemm_ks_kernel)<[^>]*>", k)
+        if m:
+            inst[m.group(0)] = {"bytes_per_launch": round(tot * 1e9 / n, -5), "launches": n}
+    out["by_instantiation"] = inst
     if out and len(sys.argv) > 4:
         json.dump(out, open(sys.argv[4], "w"), indent=1)
 
