@@ -186,6 +186,11 @@ int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot, const flo
  * (_get_orig_video_res_output, sam2_video_predictor_official.py:489-509). */
 int sam2mi_resize_bilinear(sam2mi_ctx* ctx, void* stream, const float* in, int C, int Hin, int Win, float* out, int Hout, int Wout);
 
+/* A HIP stream whose kernels never run on `reserve` (0..16) of the CUs, 2 per XCD at 16 (hipExtStreamCreateWithCUMask): the
+ * encoder prefetch stream of the video predictor, so that the small kernels of the tracking path always find free CUs. */
+int sam2mi_stream_create_reserved(sam2mi_ctx* ctx, int reserve, void** stream_out);
+int sam2mi_stream_destroy(sam2mi_ctx* ctx, void* stream);
+
 /* Profiling hook for bench.py: when enabled, every MFMA GEMM launch is bracketed by HIP events on its
  * own stream; totals are read back with sam2mi_profile_read (synchronises). */
 int sam2mi_profile_enable(sam2mi_ctx* ctx, int on);

@@ -160,6 +160,35 @@ extern "C" int sam2mi_dense_pe(sam2mi_ctx* ctx, void* stream, float* out) {
   return 0;
 }
 
+// HIP stream restricted to a subset of the CUs (hipExtStreamCreateWithCUMask).  `reserve` CUs are left OUT of the mask, spread
+// evenly over the 8 XCDs whichever way the mask bits map to them (bit 16 k + k % 16, k = 0 .. reserve-1 cleared per 256 bits):
+// kernels on this stream never occupy them, so small kernels of another stream always find free CUs.
+extern "C" int sam2mi_stream_create_reserved(sam2mi_ctx* ctx, int reserve, void** stream_out) {
+  if (!ctx || !stream_out) return 1;
+  hipDeviceProp_t prop;
+  int dev = 0;
+  CHK(hipGetDevice(&dev));
+  CHK(hipGetDeviceProperties(&prop, dev));
+  const int ncu = prop.multiProcessorCount;
+  if (reserve < 0 || reserve > 16 || ncu < 256) return sam2mi_set_error(ctx, __func__, "reserve must be 0..16 on a 256-CU device");
+  const int nwords = (ncu + 31) / 32;
+  std::vector<uint32_t> mask(nwords, 0xFFFFFFFFu);
+  if (ncu % 32) mask[nwords - 1] = (1u << (ncu % 32)) - 1u;
+  for (int k = 0; k < reserve; ++k) {
+    const int bit = 16 * k + (k % 16);
+    mask[bit / 32] &= ~(1u << (bit % 32));
+  }
+  hipStream_t st = nullptr;
+  CHK(hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask.data()));
+  *stream_out = (void*)st;
+  return 0;
+}
+extern "C" int sam2mi_stream_destroy(sam2mi_ctx* ctx, void* stream) {
+  if (!ctx) return 1;
+  if (stream) CHK(hipStreamDestroy((hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int sam2mi_resize_bilinear(sam2mi_ctx* ctx, void* stream, const float* in, int C, int Hin, int Win, float* out, int Hout, int Wout) {
   if (!ctx) return 1;
   const size_t n = (size_t)C * Hout * Wout;

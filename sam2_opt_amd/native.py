@@ -19,7 +19,7 @@ EXPORTS = [
     "sam2mi_finalize_weights", "sam2mi_image_encoder", "sam2mi_set_image_e2e", "sam2mi_memory_attention",
     "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_dense_pe", "sam2mi_video_encode", "sam2mi_video_encode_u8", "sam2mi_fill_holes", "sam2mi_set_fill_hole_area",
     "sam2mi_video_click", "sam2mi_video_mask", "sam2mi_image_predict", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_video_track_batch", "sam2mi_resize_bilinear",
-    "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_profile_read_mlp", "sam2mi_profile_read_xs", "sam2mi_profile_read_ks", "sam2mi_profile_read_kernels", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
+    "sam2mi_stream_create_reserved", "sam2mi_stream_destroy", "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_profile_read_mlp", "sam2mi_profile_read_xs", "sam2mi_profile_read_ks", "sam2mi_profile_read_kernels", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
     "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench", "sam2mi_debug_mlp",
 ]
 
@@ -329,6 +329,13 @@ class Engine:
         return dict(gemm_ms=v[0].value, gemm_flops=v[1].value, gemm_launches=v[2].value, attn_ms=v[3].value,
                     attn_flops=v[4].value, attn_launches=v[5].value, mlp_ms=m[0].value, mlp_flops=m[1].value,
                     mlp_launches=m[2].value, xs_ms=x[0].value, xs_flops=x[1].value, xs_launches=x[2].value, **self._prof3("ks"))
+
+    def create_reserved_stream(self, reserve: int):
+        """torch.cuda.ExternalStream over a HIP stream that leaves `reserve` CUs (spread over the XCDs) to other streams."""
+        h = C.c_void_p()
+        self._check(self.lib.sam2mi_stream_create_reserved(self.h, int(reserve), C.byref(h)), "sam2mi_stream_create_reserved")
+        self._ext_streams = getattr(self, "_ext_streams", []) + [h]
+        return torch.cuda.ExternalStream(h.value, device=self.device)
 
     def profile_read_kernels(self) -> dict:
         """{kernel instantiation name: dict(ms, flops, launches)} of the GEMM-family launches since profile_enable(True)."""

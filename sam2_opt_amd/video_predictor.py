@@ -55,7 +55,13 @@ class SAM2VideoPredictor:
         self.overlap_encode = bool(overlap_encode)
         import os as _os
         _prio = int(_os.environ.get("SAM2MI_ENC_PRIORITY", "0"))      # tuning: -1 = high-priority encoder stream
-        self._enc_stream = torch.cuda.Stream(device=self.device, priority=_prio) if self.overlap_encode else None
+        _reserve = int(_os.environ.get("SAM2MI_ENC_RESERVE_CUS", "0"))   # CUs the encoder stream leaves to the tracking path
+        if not self.overlap_encode:
+            self._enc_stream = None
+        elif _reserve > 0:
+            self._enc_stream = self.engine.create_reserved_stream(_reserve)
+        else:
+            self._enc_stream = torch.cuda.Stream(device=self.device, priority=_prio)
         self.backend = "hip"
         self.debug_trace = None      # set to {} to record per-frame intermediates (parity tests)
 
