@@ -373,7 +373,7 @@ extern "C" int sam2mi_profile_read_kernels(sam2mi_ctx* ctx, char* out, int cap) 
   std::string sout;
   for (auto& kv : ctx->prof_by_kernel) {
     char line[256];
-    snprintf(line, sizeof(line), "%s\t%.6f\t%.6e\t%lld\n", kv.first.c_str(), kv.second.ms, kv.second.flops, (long long)kv.second.launches);
+    snprintf(line, sizeof(line), "%s\t%.9f\t%.17g\t%lld\n", kv.first.c_str(), kv.second.ms, kv.second.flops, (long long)kv.second.launches);
     sout += line;
   }
   if ((int)sout.size() + 1 > cap) return -1;

@@ -149,3 +149,37 @@ def test_gemm_ks(eng, M, K, res):
     if res:
         ref = ref + R.double()
     check(f"gemm_ks {M}x{N}x{K}", out, ref.float(), 1e-4, 1e-5)
+
+
+def test_profile_by_kernel_instantiation(eng):
+    """sam2mi_profile_read_kernels: the per-instantiation accumulators (what bench.py's roofline object is built from) carry
+    the rocprofv3 kernel names and add up to the family totals of sam2mi_profile_read."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = r16(torch.randn(4096, 256, generator=g)).cuda()
+    W = r16(torch.randn(512, 256, generator=g) / 16).cuda()
+    b = torch.zeros(512).cuda()
+    eng.profile_enable(True)
+    for _ in range(3):
+        eng.debug_gemm(A, W, b, 0, None)
+    tot = eng.profile_read()
+    per = eng.profile_read_kernels()
+    eng.profile_enable(False)
+    assert tot["gemm_launches"] == 3 and len(per) == 1
+    (name, v), = per.items()
+    assert name.startswith("gemm_v2_kernel<") and v["launches"] == 3
+    assert abs(v["ms"] - tot["gemm_ms"]) < 1e-6 and v["flops"] == 3 * 2.0 * 4096 * 512 * 256
+
+
+def test_reserved_cu_stream(eng):
+    """sam2mi_stream_create_reserved: a CU-masked HIP stream is usable as a torch stream and computes the same GEMM."""
+    g = torch.Generator(device="cpu").manual_seed(6)
+    A = r16(torch.randn(512, 256, generator=g)).cuda()
+    W = r16(torch.randn(256, 256, generator=g) / 16).cuda()
+    b = torch.randn(256, generator=g).cuda()
+    ref = eng.debug_gemm(A, W, b, 0, None)
+    st = eng.create_reserved_stream(8)
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        out = eng.debug_gemm(A, W, b, 0, None)
+    st.synchronize()
+    assert torch.equal(out, ref)
