@@ -271,12 +271,12 @@ hipError_t attr_cfg() {
 }  // namespace
 
 // Configurations: C = 144: 64 tokens per wave (256 per workgroup), 19 + 1 padding pieces per chunk, 4-slot ring (82 KiB);
-// C = 288: 32 tokens per wave (128 per workgroup), 36 pieces per chunk, 4-slot ring (149 KiB).
+// C = 288: 32 tokens per wave (128 per workgroup), 36 pieces per chunk, 3-slot ring (113 KiB).
 // C = 576 does not fit: 32 tokens need 144 (X) + 288 (Y^T) of the 512 registers and the compiler spills X into scratch
 // (reloaded inside the MFMA chains behind vmcnt(0), which also drains the DMA ring) - stage 3 stays on the two-GEMM path.
 hipError_t mlp_fused_init() {
-  hipError_t e[2] = {attr_cfg<144, 2, 4>(), attr_cfg<288, 1, 4>()};
-  for (int i = 0; i < 2; ++i)
+  hipError_t e[3] = {attr_cfg<144, 2, 4>(), attr_cfg<288, 1, 4>(), attr_cfg<288, 1, 3>()};
+  for (int i = 0; i < 3; ++i)
     if (e[i] != hipSuccess) return e[i];
   return hipSuccess;
 }
@@ -298,12 +298,16 @@ hipError_t mlp_fused_pack(const half_t* w1, const half_t* w2, int C, half_t* wpa
   return hipGetLastError();
 }
 
+// C = 288: a 3-slot ring (113 KB) runs the kernel at the same speed as 4 slots (149 KB) and leaves LDS for a small workgroup of the
+// tracking stream beside it (+0.7 % end to end); SAM2MI_MLP_RING4=1 restores 4 slots
+static bool ring4() { static const bool v = getenv("SAM2MI_MLP_RING4") != nullptr; return v; }
+
 hipError_t mlp_fused_launch(const MlpFusedParams& p, int C, hipStream_t s) {
   if (p.M <= 0) return hipSuccess;
   if ((p.ldx & 7) || (p.ld32 & 3)) return hipErrorInvalidValue;
   switch (C) {
     case 144: return launch_cfg<144, 2, 4>(p, s);
-    case 288: return launch_cfg<288, 1, 4>(p, s);
+    case 288: return ring4() ? launch_cfg<288, 1, 4>(p, s) : launch_cfg<288, 1, 3>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
