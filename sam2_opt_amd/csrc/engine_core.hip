@@ -123,11 +123,7 @@ int run_mlp_fused(sam2mi_ctx* ctx, hipStream_t s, const MlpFusedParams& p, int C
   hipEvent_t e0, e1;
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_mlp, s, e0, e1);
   CHK(mlp_fused_launch(p, C, s));
-  if (ctx->prof_on) {
-    char nm[64];
-    snprintf(nm, sizeof(nm), "mlp_fused_kernel<%d, %d, 4>", C, C == 144 ? 2 : 1);
-    prof_end_named(ctx, ctx->prof_mlp, nm, s, e0, e1, 2.0 * 2.0 * p.M * (double)C * (4.0 * C));   // fc1 + fc2
-  }
+  if (ctx->prof_on) prof_end_named(ctx, ctx->prof_mlp, mlp_fused_kernel_name(C), s, e0, e1, 2.0 * 2.0 * p.M * (double)C * (4.0 * C));   // fc1 + fc2
   return 0;
 }
 int run_hiera_attn(sam2mi_ctx* ctx, hipStream_t s, const HieraAttnParams& p) {

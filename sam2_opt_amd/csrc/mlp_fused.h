@@ -15,4 +15,5 @@ bool mlp_fused_supported(int C);                     // C in {144, 288}
 size_t mlp_fused_pack_bytes(int C);
 hipError_t mlp_fused_pack(const half_t* w1, const half_t* w2, int C, half_t* wpack, hipStream_t s);
 hipError_t mlp_fused_launch(const MlpFusedParams& p, int C, hipStream_t s);
+const char* mlp_fused_kernel_name(int C);            // kernel instantiation launched for C, as rocprofv3 prints it
 hipError_t mlp_fused_init();                         // dynamic-LDS attributes, once

@@ -302,6 +302,11 @@ hipError_t mlp_fused_pack(const half_t* w1, const half_t* w2, int C, half_t* wpa
 // tracking stream beside it (+0.7 % end to end); SAM2MI_MLP_RING4=1 restores 4 slots
 static bool ring4() { static const bool v = getenv("SAM2MI_MLP_RING4") != nullptr; return v; }
 
+const char* mlp_fused_kernel_name(int C) {       // as rocprofv3 prints it
+  if (C == 144) return "mlp_fused_kernel<144, 2, 4>";
+  return ring4() ? "mlp_fused_kernel<288, 1, 4>" : "mlp_fused_kernel<288, 1, 3>";
+}
+
 hipError_t mlp_fused_launch(const MlpFusedParams& p, int C, hipStream_t s) {
   if (p.M <= 0) return hipSuccess;
   if ((p.ldx & 7) || (p.ld32 & 3)) return hipErrorInvalidValue;
