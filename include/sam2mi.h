@@ -38,7 +38,13 @@ typedef struct sam2mi_config {
   int max_batch;             /* largest B of sam2mi_image_encoder / sam2mi_video_encode (workspace size) */
   int bank_slots;            /* capacity of the device-resident memory bank of the video path */
   int feat_slots;            /* capacity of the device-resident frame-feature cache of the video path */
+  int precision;             /* SAM2MI_PRECISION_F16 (0, default): f16 MFMA operands, f32 accumulate - masks within ~2e-3 of the
+                              * reference's fp32 torch path; SAM2MI_PRECISION_F16X3 (1): every MFMA operand is carried as a
+                              * 2-term f16 split (hi + lo) and every product costs three MFMAs - the north-star "within 1e-3"
+                              * class (measured <= 1e-4 per plug), about 2-3x the MFMA work */
 } sam2mi_config;
+#define SAM2MI_PRECISION_F16 0
+#define SAM2MI_PRECISION_F16X3 1
 
 int sam2mi_abi_version(void);
 int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out);

@@ -2,7 +2,7 @@
 from /root/reference on seeded synthetic inputs and weights.  Container-only; the
 outputs (data, not code) are committed and travel to the GPU box.
 
-    python -m oracle.gen_golden [plugs] [video] [tiny] [interact] [reverse]
+    python -m oracle.gen_golden [plugs] [video] [tiny] [interact] [reverse] [multi] [box] [long]
 
 Weights: sam2_opt_amd.weights.synthetic_state_dict(cfg, seed=0)   (regenerated anywhere)
 Inputs : sam2_opt_amd.synthetic.*  with the seeds named below.
@@ -27,6 +27,7 @@ from sam2_opt_amd.weights import synthetic_state_dict  # noqa: E402
 GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 BLOCKS = (0, 1, 2, 3, 7, 8, 9, 23, 43, 44, 47)
 VIDEO_FRAMES = 24
+FULL_FRAMES = (7, 15, 23)       # video-res masks stored in full (f16) in large_video24_full.npz
 CLICK = (512.0, 512.0)
 
 
@@ -100,6 +101,7 @@ def gen_video():
     import sam2.sam2_video_predictor_official as vp
     vp.load_video_frames = lambda **kw: (frames, 1024, 1024)
     store = {}
+    full = {}                   # second file: EVERY pixel - low-res logits of all frames (f32), three video-res frames (f16)
     rec = {"t": None}
     ma = model.memory_attention
     orig_ex = ma.inference_memory_attention_exclude
@@ -145,10 +147,15 @@ def gen_video():
         out = state["output_dict_per_obj"][0]
         cur = out["cond_frame_outputs"].get(fi) or out["non_cond_frame_outputs"][fi]
         pack(store, f"f{fi}/maskmem_features", cur["maskmem_features"].float(), 8192)
+        full[f"f{fi}/pred_masks"] = cur["pred_masks"].float().cpu().numpy()
+        if fi in FULL_FRAMES:
+            full[f"f{fi}/video_res_mask_f16"] = vm.float().cpu().numpy().astype(np.float16)
         print("frame", fi, time.time() - t0, flush=True)
         n += 1
     store["num_frames"] = np.array([n], dtype=np.int64)
     np.savez_compressed(os.path.join(GOLD, "large_video24.npz"), **store)
+    full["num_frames"] = np.array([n], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "large_video24_full.npz"), **full)
     print("video done", time.time() - t0)
 
 
@@ -221,6 +228,121 @@ def gen_reverse():
     print("reverse done", order)
 
 
+MULTI_FRAMES = 8
+MULTI_CLICKS = {1: (0, (512.0, 512.0)), 2: (0, (300.0, 700.0)), 3: (2, (760.0, 260.0))}      # obj_id -> (frame, click)
+
+
+def _video_model(seed, num_frames, **kw):
+    cfg = get_config("large")
+    sd = synthetic_state_dict(cfg, seed=0)
+    model = build_reference_model(cfg, "video", sd, fill_hole_area=0, **kw)
+    frames = normalize_frames(synthetic_frames_u8(seed=seed, num_frames=num_frames), cfg)
+    import sam2.sam2_video_predictor_official as vp
+    vp.load_video_frames = lambda **k: (frames, 1024, 1024)
+    return model
+
+
+@torch.inference_mode()
+def gen_multi():
+    """Multi-object tracking through the reference's per-object loop (sam2_video_predictor_official.py:691-725) and
+    _consolidate_temp_output_across_obj / non-overlap logic: scenario A = objects 1 and 2 clicked on frame 0; scenario B adds
+    object 3 with its click on frame 2 (staggered prompts: on frames 0-1 object 3 is tracked from its FUTURE conditioning frame);
+    scenario C = scenario A with non_overlap_masks=True.  Per frame: the (num_obj,1,H,W) video-res masks (sampled) and every
+    object's low-res logits of frames 3 and 7 in full."""
+    store = {}
+    t0 = time.time()
+    for tag, objs, kw in (("A", (1, 2), {}), ("B", (1, 2, 3), {}), ("C", (1, 2), {"non_overlap_masks": True})):
+        model = _video_model(8, MULTI_FRAMES, **kw)
+        state = model.init_state(video_path="synthetic")
+        for oid in objs:
+            fr, pt = MULTI_CLICKS[oid]
+            _, ids, vm = model.add_new_points_or_box(state, frame_idx=fr, obj_id=oid, points=np.array([pt], np.float32),
+                                                     labels=np.array([1], np.int32))
+            pack(store, f"{tag}/click{oid}/video_res_mask", vm, 16384)
+            store[f"{tag}/click{oid}/obj_ids"] = np.array(ids, dtype=np.int64)
+        for fi, ids, vm in model.propagate_in_video(state):
+            pack(store, f"{tag}/f{fi}/video_res_mask", vm, 16384)
+            store[f"{tag}/f{fi}/obj_ids"] = np.array(ids, dtype=np.int64)
+            if fi in (3, 7):
+                for k in range(len(objs)):
+                    od = state["output_dict_per_obj"][k]
+                    cur = od["cond_frame_outputs"].get(fi) or od["non_cond_frame_outputs"][fi]
+                    store[f"{tag}/f{fi}/obj{k}/pred_masks"] = cur["pred_masks"].float().cpu().numpy()
+            print("multi", tag, "frame", fi, time.time() - t0, flush=True)
+    np.savez_compressed(os.path.join(GOLD, "large_multi8.npz"), **store)
+    print("multi done", time.time() - t0)
+
+
+BOX = (300.0, 380.0, 720.0, 800.0)       # x0, y0, x1, y1
+
+
+@torch.inference_mode()
+def gen_box():
+    """Box prompts (labels 2 / 3, sam2_video_predictor_official.py:300-316; prompt_encoder.py:_embed_points with the corner
+    embeddings): a box on frame 0; a box + one positive point in the same call on frame 0 of a second run; 4 frames each.
+    Also the prompt-encoder plug on (points, boxes, None) directly (PromptEncoder.inference_prompt_torch, :215-231)."""
+    store = {}
+    t0 = time.time()
+    for tag, pts in (("box", None), ("boxpt", np.array([[500.0, 600.0]], np.float32))):
+        model = _video_model(12, 4)
+        state = model.init_state(video_path="synthetic")
+        _, ids, vm = model.add_new_points_or_box(state, frame_idx=0, obj_id=1, box=np.array(BOX, np.float32), points=pts,
+                                                 labels=None if pts is None else np.array([1], np.int32))
+        pack(store, f"{tag}/click/video_res_mask", vm, 16384)
+        cur = state["temp_output_dict_per_obj"][0]["cond_frame_outputs"][0]
+        store[f"{tag}/click/pred_masks"] = cur["pred_masks"].float().cpu().numpy()
+        pack(store, f"{tag}/click/obj_ptr", cur["obj_ptr"], 256)
+        for fi, ids, vm in model.propagate_in_video(state):
+            pack(store, f"{tag}/f{fi}/video_res_mask", vm, 16384)
+            print("box", tag, "frame", fi, time.time() - t0, flush=True)
+    pe = model.sam_prompt_encoder
+    pts = (torch.tensor([[[100.0, 200.0], [512.0, 512.0]], [[7.5, 900.0], [640.0, 32.0]]]), torch.tensor([[1, 0], [1, 1]], dtype=torch.int32))
+    boxes = torch.tensor([[10.0, 20.0, 300.0, 400.0], [512.0, 512.0, 1000.0, 900.0]])
+    sp, de = pe.inference_prompt_torch(pts, boxes, None)
+    pack(store, "plug/points_boxes/sparse", sp)
+    sp, de = pe.inference_prompt_torch(None, boxes, None)
+    pack(store, "plug/boxes/sparse", sp)
+    mask_in = randn(77, 2, 1, 256, 256, scale=3.0)
+    sp, de = pe.inference_prompt_torch(pts, None, mask_in)
+    pack(store, "plug/points_mask/sparse", sp)
+    pack(store, "plug/points_mask/dense", de, 65536)
+    np.savez_compressed(os.path.join(GOLD, "large_box4.npz"), **store)
+    print("box done", time.time() - t0)
+
+
+LONG_FRAMES = 32
+LONG_CLICK_FRAME = 16
+
+
+@torch.inference_mode()
+def gen_long():
+    """Clip longer than the pointer horizon (16) + the memory horizon (7): click in the MIDDLE (frame 16), propagate forward to
+    the end, then propagate_in_video(reverse=True) from the click back to frame 0 (frame 15 attends to the forward pass's
+    memories of frames 17..22, sam2_base_official.py:843-864), then a correction click on frame 5 - more than 17 frames
+    behind the forward head - and its re-tracking of frames 6..9.  ADVICE r01: slots of old frames must survive."""
+    store = {}
+    t0 = time.time()
+    model = _video_model(14, LONG_FRAMES)
+    state = model.init_state(video_path="synthetic")
+    _, _, vm = model.add_new_points_or_box(state, frame_idx=LONG_CLICK_FRAME, obj_id=1, points=np.array([CLICK], np.float32),
+                                           labels=np.array([1], np.int32))
+    pack(store, "click/video_res_mask", vm, 16384)
+    for fi, ids, vm in model.propagate_in_video(state):
+        pack(store, f"fwd/f{fi}/video_res_mask", vm, 8192)
+        print("long fwd", fi, time.time() - t0, flush=True)
+    for fi, ids, vm in model.propagate_in_video(state, reverse=True):
+        pack(store, f"rev/f{fi}/video_res_mask", vm, 8192)
+        print("long rev", fi, time.time() - t0, flush=True)
+    _, _, vm = model.add_new_points_or_box(state, frame_idx=5, obj_id=1, points=np.array([[420.0, 640.0]], np.float32),
+                                           labels=np.array([0], np.int32))
+    pack(store, "fix5/video_res_mask", vm, 16384)
+    for fi, ids, vm in model.propagate_in_video(state, start_frame_idx=6, max_frame_num_to_track=3):
+        pack(store, f"fix/f{fi}/video_res_mask", vm, 8192)
+        print("long fix", fi, time.time() - t0, flush=True)
+    np.savez_compressed(os.path.join(GOLD, "large_long32.npz"), **store)
+    print("long done", time.time() - t0)
+
+
 @torch.inference_mode()
 def gen_tiny():
     """BASELINE.json configs[0]: SAM2.1-hiera-tiny image predictor, one 1024^2 frame, torch backend on the CPU - the
@@ -258,3 +380,9 @@ if __name__ == "__main__":
         gen_interact()
     if "reverse" in which:
         gen_reverse()
+    if "multi" in which:
+        gen_multi()
+    if "box" in which:
+        gen_box()
+    if "long" in which:
+        gen_long()

@@ -3,9 +3,10 @@
 Follows fill_holes_in_mask_scores (/root/reference/sam2/sam2/utils/misc.py:312-338) and the contract of
 get_connected_components (:47-62): 8-connectivity components of the background (score <= 0); components of area
 <= max_area are set to 0.1.  The reference computes the components with its CUDA extension
-(csrc/connected_components.cu), which cannot be built here (no CUDA) - PARITY UNPINNED against the reference's
-own kernel; this restatement uses scipy.ndimage.label, an independent implementation of the same definition, and
-is pinned by the hand-made known-answer cases in tests/test_postproc.py.
+(csrc/connected_components.cu), which cannot be built here (no CUDA).  This file uses scipy.ndimage.label, an
+independent implementation of the same definition; it is pinned (a) by hand-made known-answer cases and (b) against
+oracle/cc_blockuf.py, the stage-by-stage CPU restatement of that CUDA kernel's block-based union-find: identical
+partitions and per-pixel areas on random and adversarial masks (tests/test_postproc.py).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this module.
 """
 import numpy as np

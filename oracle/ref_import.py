@@ -81,7 +81,7 @@ def import_reference():
     return sam2
 
 
-def build_reference_model(cfg: dict, kind: str = "video", state_dict=None, fill_hole_area: int = 0):
+def build_reference_model(cfg: dict, kind: str = "video", state_dict=None, fill_hole_area: int = 0, **predictor_kw):
     """Instantiate the reference model tree by hand (what hydra `instantiate` would do
     for configs/sam2.1/sam2.1_hiera_*.yaml plus the overrides of build_sam.py:81-88 /
     :110-131).  kind: "video" -> SAM2VideoPredictor, "base" -> SAM2Base."""
@@ -144,7 +144,7 @@ def build_reference_model(cfg: dict, kind: str = "video", state_dict=None, fill_
     if kind == "video":
         model = SAM2VideoPredictor(fill_hole_area=fill_hole_area,
                                    binarize_mask_from_pts_for_mem_enc=cfg["binarize_mask_from_pts_for_mem_enc"],
-                                   **kwargs)
+                                   **predictor_kw, **kwargs)       # predictor_kw: non_overlap_masks, clear_non_cond_mem_around_input, ...
     elif kind == "base":
         model = SAM2Base(**kwargs)
     else:

@@ -16,6 +16,20 @@ struct HieraAttnParams {
 };
 hipError_t hiera_attn_launch(const HieraAttnParams& p, hipStream_t stream);
 
+// ---- head_dim-72 attention of the f16x3 precision mode (attn_precise.hip): same grouping / masking as HieraAttnParams, but
+// q, k, V^T arrive as f32 (the QKV GEMM's f32 outputs) and are split into hi + lo f16 MFMA operands in registers:
+// S = K Q^T with 3 products, O += V^T P^T with V split (2 products), P in f16; output written as hi + lo at o / o + o_lo_off.
+struct PreciseAttnParams {
+  const float* q; int ldq;      // [Mq, ldq] f32, pre-scaled by head_dim^-0.5 * log2(e); head h at columns [h*72, h*72+72)
+  const float* k; int ldk;      // [Mk, ldk] f32
+  const float* vT; int ldvT;    // V^T [heads*72, ldvT] f32
+  half_t* o; int ldo;           // [Mq, ldo] f16 hi plane
+  size_t o_lo_off;              // lo plane offset (elements), must be non-zero
+  int heads;
+  int GQ, GK, wq, wk, num_groups;   // as HieraAttnParams
+};
+hipError_t precise_attn_launch(const PreciseAttnParams& p, hipStream_t stream);
+
 // ---- single-head d=256 flash attention with split-KV (attn_flash256.hip)
 struct Flash256Params {
   const half_t* q; int ldq;     // [Nq, ldq] f16, RoPE applied and PRE-SCALED by 256^-0.5 * log2(e); Nq % 128 == 0
@@ -27,6 +41,7 @@ struct Flash256Params {
   float* ml_part;               // [splits, Nq, 2] f32 (running max in log2 domain, running sum)
   half_t* out; int ldout;       // [Nq, ldout] f16 final (written by the combine pass)
   float scale_log2e;            // unused by the kernel (q is pre-scaled); kept for the debug entry point
+  size_t out_lo_off;            // split-f16 mode: `out` is written as hi + lo (common.h); 0: off
 };
 hipError_t flash256_launch(const Flash256Params& p, hipStream_t stream);
 hipError_t flash256_init();   // dynamic-LDS attribute, once

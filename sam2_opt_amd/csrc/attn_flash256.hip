@@ -31,6 +31,7 @@ constexpr int STAGE_B = K_TILE_B + V_TILE_B;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+#ifdef SAM2MI_EXPERIMENTAL      // v2: 2 waves per SIMD, register-starved; kept for A/B runs (SAM2MI_FLASH_V2)
 __global__ __launch_bounds__(256, 2) void flash256_kernel(const Flash256Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void flash256_kernel(const Flash256Params p
     ml[1] = l_run;
   }
 }
+#endif  // SAM2MI_EXPERIMENTAL
 
 // ---------------------------------------------------------------------------------------------------------------
 // v3: one workgroup per CU, one wave per SIMD (up to 512 registers per lane).  The 2-waves-per-SIMD kernel above is
@@ -431,12 +433,13 @@ __global__ __launch_bounds__(256) void flash256_combine_kernel(const Flash256Par
     acc[0] += w * v[0]; acc[1] += w * v[1]; acc[2] += w * v[2]; acc[3] += w * v[3];
   }
   const float inv = 1.f / L;
-  const half4 h = {(half_t)(acc[0] * inv), (half_t)(acc[1] * inv), (half_t)(acc[2] * inv), (half_t)(acc[3] * inv)};
-  *reinterpret_cast<half4*>(p.out + (size_t)q * p.ldout + d) = h;
+  const f32x4 o = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+  store_h4(p.out + (size_t)q * p.ldout + d, p.out_lo_off, o);
 }
 }  // namespace
 
 hipError_t flash256_init() {
+#ifdef SAM2MI_EXPERIMENTAL
   const void* v3[9] = {reinterpret_cast<const void*>(&flash256_v3_kernel<0, false, 4>), reinterpret_cast<const void*>(&flash256_v3_kernel<0, true, 4>),
                        reinterpret_cast<const void*>(&flash256_v3_kernel<0, false, 3>), reinterpret_cast<const void*>(&flash256_v3_kernel<0, true, 3>),
                        reinterpret_cast<const void*>(&flash256_v3_kernel<1, true, 4>), reinterpret_cast<const void*>(&flash256_v3_kernel<2, true, 4>),
@@ -447,12 +450,24 @@ hipError_t flash256_init() {
     if (e != hipSuccess) return e;
   }
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&flash256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B);
+#else
+  const void* v3[2] = {reinterpret_cast<const void*>(&flash256_v3_kernel<0, false, 4>), reinterpret_cast<const void*>(&flash256_v3_kernel<0, true, 4>)};
+  for (int i = 0; i < 2; ++i) {
+    hipError_t e = hipFuncSetAttribute(v3[i], hipFuncAttributeMaxDynamicSharedMemorySize, NST_MAX * STAGE3_B);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+#endif
 }
 
 // v3 runs one 128-query workgroup per CU: pick the KV split count that makes the grid one full wave of 256 workgroups
 int flash256_pick_splits(int Nq, int Nk) {
   const int tiles = (Nk + 31) / 32, qblocks = Nq / 128 > 0 ? Nq / 128 : 1;
+#ifdef SAM2MI_EXPERIMENTAL
   static const int target_wgs = getenv("SAM2MI_FLASH_WGS") ? atoi(getenv("SAM2MI_FLASH_WGS")) : 256;     // tuning
+#else
+  const int target_wgs = 256;
+#endif
   int s = (target_wgs + qblocks - 1) / qblocks;
   if (s > 16) s = 16;
   if (s > tiles) s = tiles;
@@ -461,28 +476,27 @@ int flash256_pick_splits(int Nq, int Nk) {
 
 hipError_t flash256_launch(const Flash256Params& p, hipStream_t stream) {
   if (p.Nq % 128 || p.Nk <= 0 || p.splits <= 0 || (p.ldq & 7) || (p.ldk & 7) || (p.ldvT & 7) || (p.ldout & 3)) return hipErrorInvalidValue;
+  const dim3 grid((p.Nq / 128) * p.splits), block(256);
+#ifdef SAM2MI_EXPERIMENTAL
   static const bool use_v2 = getenv("SAM2MI_FLASH_V2") != nullptr;      // A/B switch: the 2-waves-per-SIMD kernel
-  if (use_v2) flash256_kernel<<<dim3(p.Nq / 128, p.splits), dim3(256), 2 * STAGE_B, stream>>>(p);
-  else {
-    static const int abl = getenv("SAM2MI_FLASH_ABL") ? atoi(getenv("SAM2MI_FLASH_ABL")) : 0;     // tuning only
-    const dim3 grid((p.Nq / 128) * p.splits), block(256);
-    static const int nst = getenv("SAM2MI_FLASH_STAGES") ? atoi(getenv("SAM2MI_FLASH_STAGES")) : 4;   // 3: 100 KB ring (tuning)
+  static const int abl = getenv("SAM2MI_FLASH_ABL") ? atoi(getenv("SAM2MI_FLASH_ABL")) : 0;     // tuning only (wrong results)
+  static const int nst = getenv("SAM2MI_FLASH_STAGES") ? atoi(getenv("SAM2MI_FLASH_STAGES")) : 4;   // 3: 100 KB ring (tuning)
+  if (use_v2 || abl || nst == 3) {
     const size_t lds = (size_t)(nst == 3 ? 3 : 4) * STAGE3_B;
-    switch (abl) {
-      case 1: flash256_v3_kernel<1, true, 4><<<grid, block, lds, stream>>>(p); break;
-      case 2: flash256_v3_kernel<2, true, 4><<<grid, block, lds, stream>>>(p); break;
-      case 3: flash256_v3_kernel<3, true, 4><<<grid, block, lds, stream>>>(p); break;
-      case 4: flash256_v3_kernel<4, true, 4><<<grid, block, lds, stream>>>(p); break;
-      case 5: flash256_v3_kernel<5, true, 4><<<grid, block, lds, stream>>>(p); break;
-      default:
-        if (nst == 3) {
-          if (p.Nk % 32) flash256_v3_kernel<0, true, 3><<<grid, block, lds, stream>>>(p);
-          else flash256_v3_kernel<0, false, 3><<<grid, block, lds, stream>>>(p);
-        } else {
-          if (p.Nk % 32) flash256_v3_kernel<0, true, 4><<<grid, block, lds, stream>>>(p);
-          else flash256_v3_kernel<0, false, 4><<<grid, block, lds, stream>>>(p);
-        }
-    }
+    if (use_v2) flash256_kernel<<<dim3(p.Nq / 128, p.splits), dim3(256), 2 * STAGE_B, stream>>>(p);
+    else if (abl == 1) flash256_v3_kernel<1, true, 4><<<grid, block, lds, stream>>>(p);
+    else if (abl == 2) flash256_v3_kernel<2, true, 4><<<grid, block, lds, stream>>>(p);
+    else if (abl == 3) flash256_v3_kernel<3, true, 4><<<grid, block, lds, stream>>>(p);
+    else if (abl == 4) flash256_v3_kernel<4, true, 4><<<grid, block, lds, stream>>>(p);
+    else if (abl == 5) flash256_v3_kernel<5, true, 4><<<grid, block, lds, stream>>>(p);
+    else if (p.Nk % 32) flash256_v3_kernel<0, true, 3><<<grid, block, lds, stream>>>(p);
+    else flash256_v3_kernel<0, false, 3><<<grid, block, lds, stream>>>(p);
+  } else
+#endif
+  {
+    const size_t lds = (size_t)4 * STAGE3_B;
+    if (p.Nk % 32) flash256_v3_kernel<0, true, 4><<<grid, block, lds, stream>>>(p);
+    else flash256_v3_kernel<0, false, 4><<<grid, block, lds, stream>>>(p);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

@@ -45,6 +45,26 @@ static __device__ __forceinline__ float gelu_erf_fast(float x) {
   return fmaf(-ax, poly * t * e, fmaxf(x, 0.0f));
 }
 
+// ---- split-f16 ("f16x3") precision mode: an f32 value v travels as hi = f16(v) and lo = f16((v - hi) * 2^11); the lo array
+// sits `lo_off` elements behind the hi array (one arena offset for every f16 activation buffer, 0 = mode off).  The scale
+// keeps lo in the normal f16 range whenever hi is; a product of two split values is hi*hi + (hi*lo + lo*hi) * 2^-11.
+#define SPLIT_SCALE 2048.0f
+#define SPLIT_INV (1.0f / 2048.0f)
+static __device__ __forceinline__ half_t split_lo(float v, half_t hi) { return (half_t)((v - (float)hi) * SPLIT_SCALE); }
+static __device__ __forceinline__ void store_h1(half_t* p, size_t lo_off, float v) {
+  const half_t h = (half_t)v;
+  *p = h;
+  if (lo_off) p[lo_off] = split_lo(v, h);
+}
+static __device__ __forceinline__ void store_h4(half_t* p, size_t lo_off, f32x4 v) {      // 8-byte aligned
+  const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+  *reinterpret_cast<half4*>(p) = h;
+  if (lo_off) {
+    const half4 l = {split_lo(v[0], h[0]), split_lo(v[1], h[1]), split_lo(v[2], h[2]), split_lo(v[3], h[3])};
+    *reinterpret_cast<half4*>(p + lo_off) = l;
+  }
+}
+
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

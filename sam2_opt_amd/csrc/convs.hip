@@ -25,7 +25,7 @@ __global__ void mask_prep_kernel(const float* __restrict__ low, float* __restric
 template <int CIN, int COUT>
 __global__ __launch_bounds__(128) void conv3x3s2_ln_gelu_kernel(const float* __restrict__ in, int Hin, const float* __restrict__ w,
                                                                  const float* __restrict__ b, const float* __restrict__ lnw,
-                                                                 const float* __restrict__ lnb, float* out32, half_t* out16) {
+                                                                 const float* __restrict__ lnb, float* out32, half_t* out16, size_t lo_off) {
   __shared__ float sw[COUT * CIN * 9];
   for (int i = threadIdx.x; i < COUT * CIN * 9; i += blockDim.x) sw[i] = w[i];
   __syncthreads();
@@ -65,11 +65,11 @@ __global__ __launch_bounds__(128) void conv3x3s2_ln_gelu_kernel(const float* __r
   for (int o = 0; o < COUT; ++o) {
     const float y = gelu_erf((acc[o] - mean) * rstd * lnw[o] + lnb[o]);
     if (out32) out32[(size_t)i * COUT + o] = y;
-    if (out16) out16[(size_t)i * COUT + o] = (half_t)y;
+    if (out16) store_h1(out16 + (size_t)i * COUT + o, lo_off, y);
   }
 }
 
-__global__ void im2col3x3s2_kernel(const half_t* __restrict__ in, int Hin, int CIN, half_t* __restrict__ A) {
+__global__ void im2col3x3s2_kernel(const half_t* __restrict__ in, int Hin, int CIN, half_t* __restrict__ A, size_t lo_off) {
   const int Hout = Hin / 2;
   const int cpr = 9 * CIN / 8;                       // 8-wide chunks per output row
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -79,11 +79,16 @@ __global__ void im2col3x3s2_kernel(const half_t* __restrict__ in, int Hin, int C
   const int oy = pix / Hout, ox = pix % Hout;
   const int k = ch * 8, tap = k / CIN, c = k % CIN;  // CIN % 8 == 0: a chunk never straddles taps
   const int iy = oy * 2 - 1 + tap / 3, ix = ox * 2 - 1 + tap % 3;
-  half8 v;
+  half8 v, vl;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (half_t)0.f;
-  if (iy >= 0 && iy < Hin && ix >= 0 && ix < Hin) v = *reinterpret_cast<const half8*>(in + ((size_t)iy * Hin + ix) * CIN + c);
+  for (int j = 0; j < 8; ++j) v[j] = vl[j] = (half_t)0.f;
+  const bool inside = iy >= 0 && iy < Hin && ix >= 0 && ix < Hin;
+  if (inside) v = *reinterpret_cast<const half8*>(in + ((size_t)iy * Hin + ix) * CIN + c);
   *reinterpret_cast<half8*>(A + (size_t)pix * 9 * CIN + k) = v;
+  if (lo_off) {                                        // split-f16 mode: the lo plane is gathered the same way
+    if (inside) vl = *reinterpret_cast<const half8*>(in + lo_off + ((size_t)iy * Hin + ix) * CIN + c);
+    *reinterpret_cast<half8*>(A + lo_off + (size_t)pix * 9 * CIN + k) = vl;
+  }
 }
 
 // depth-wise 7x7: one workgroup = an 8x8 pixel tile x 64 channels; the 14x14 halo patch is staged in LDS
@@ -120,24 +125,24 @@ hipError_t mask_prep_launch(const float* low, float* out, int binarize, float sc
 }
 
 hipError_t conv3x3s2_ln_gelu_launch(const float* in, int Hin, int CIN, int COUT, const float* w, const float* b,
-                                    const float* lnw, const float* lnb, float* out32, half_t* out16, hipStream_t s) {
+                                    const float* lnw, const float* lnb, float* out32, half_t* out16, hipStream_t s, size_t lo_off) {
   const int n = (Hin / 2) * (Hin / 2);
   const dim3 grid((n + 127) / 128), block(128);
   if (CIN == 1 && COUT == 4)
-    conv3x3s2_ln_gelu_kernel<1, 4><<<grid, block, 0, s>>>(in, Hin, w, b, lnw, lnb, out32, out16);
+    conv3x3s2_ln_gelu_kernel<1, 4><<<grid, block, 0, s>>>(in, Hin, w, b, lnw, lnb, out32, out16, lo_off);
   else if (CIN == 4 && COUT == 16)
-    conv3x3s2_ln_gelu_kernel<4, 16><<<grid, block, 0, s>>>(in, Hin, w, b, lnw, lnb, out32, out16);
+    conv3x3s2_ln_gelu_kernel<4, 16><<<grid, block, 0, s>>>(in, Hin, w, b, lnw, lnb, out32, out16, lo_off);
   else if (CIN == 16 && COUT == 64)
-    conv3x3s2_ln_gelu_kernel<16, 64><<<grid, block, 0, s>>>(in, Hin, w, b, lnw, lnb, out32, out16);
+    conv3x3s2_ln_gelu_kernel<16, 64><<<grid, block, 0, s>>>(in, Hin, w, b, lnw, lnb, out32, out16, lo_off);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
-hipError_t im2col3x3s2_launch(const half_t* in, int Hin, int CIN, half_t* A, hipStream_t s) {
+hipError_t im2col3x3s2_launch(const half_t* in, int Hin, int CIN, half_t* A, hipStream_t s, size_t lo_off) {
   if (CIN % 8) return hipErrorInvalidValue;
   const size_t total = (size_t)(Hin / 2) * (Hin / 2) * (9 * CIN / 8);
-  im2col3x3s2_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(in, Hin, CIN, A);
+  im2col3x3s2_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(in, Hin, CIN, A, lo_off);
   return hipGetLastError();
 }
 

@@ -11,7 +11,7 @@ namespace {
 template <int VPL>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                             const float* __restrict__ b, float eps, int M, int C,
-                                                            half_t* y16, int ldy16, float* y32, int ldy32, int act) {
+                                                            half_t* y16, int ldy16, float* y32, int ldy32, int act, size_t lo_off) {
   const int lane = threadIdx.x & 63;
   const int nv = C >> 2;                                   // float4 per row
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -62,10 +62,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
           if (act == 1) t = gelu_erf(t);
           y[e] = t;
         }
-        if (y16) {
-          const half4 h = {(half_t)y[0], (half_t)y[1], (half_t)y[2], (half_t)y[3]};
-          *reinterpret_cast<half4*>(y16 + (size_t)row * ldy16 + 4 * v) = h;
-        }
+        if (y16) store_h4(y16 + (size_t)row * ldy16 + 4 * v, lo_off, y);
         if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)row * ldy32 + 4 * v) = y;
       }
     }
@@ -75,7 +72,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
 // generic fallback (any C / alignment)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                         const float* __restrict__ b, float eps, int M, int C,
-                                                        half_t* y16, int ldy16, float* y32, int ldy32, int act) {
+                                                        half_t* y16, int ldy16, float* y32, int ldy32, int act, size_t lo_off) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= M) return;
@@ -92,14 +89,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int c = lane; c < C; c += 64) {
     float y = (xr[c] - mean) * rstd * w[c] + b[c];
     if (act == 1) y = gelu_erf(y);
-    if (y16) y16[(size_t)row * ldy16 + c] = (half_t)y;
+    if (y16) store_h1(y16 + (size_t)row * ldy16 + c, lo_off, y);
     if (y32) y32[(size_t)row * ldy32 + c] = y;
   }
 }
 
 // y = f16/f32(a + sb * b): 4 elements per thread when everything is 4-aligned
 __global__ void cast_add_vec_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int bmod,
-                                    float sb, int M, int C4, half_t* y16, int ldy16, float* y32, int ldy32) {
+                                    float sb, int M, int C4, half_t* y16, int ldy16, float* y32, int ldy32, size_t lo_off) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * C4) return;
   const int m = (int)(i / C4), c = (int)(i % C4) * 4;
@@ -108,21 +105,18 @@ __global__ void cast_add_vec_kernel(const float* __restrict__ a, int lda, const 
     const f32x4 u = *reinterpret_cast<const f32x4*>(b + (size_t)(bmod ? m % bmod : m) * ldb + c);
     v[0] += sb * u[0]; v[1] += sb * u[1]; v[2] += sb * u[2]; v[3] += sb * u[3];
   }
-  if (y16) {
-    const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-    *reinterpret_cast<half4*>(y16 + (size_t)m * ldy16 + c) = h;
-  }
+  if (y16) store_h4(y16 + (size_t)m * ldy16 + c, lo_off, v);
   if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)m * ldy32 + c) = v;
 }
 
 __global__ void cast_add_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int bmod,
-                                float sb, int M, int C, half_t* y16, int ldy16, float* y32, int ldy32) {
+                                float sb, int M, int C, half_t* y16, int ldy16, float* y32, int ldy32, size_t lo_off) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * C) return;
   const int m = (int)(i / C), c = (int)(i % C);
   float v = a[(size_t)m * lda + c];
   if (b) v += sb * b[(size_t)(bmod ? m % bmod : m) * ldb + c];
-  if (y16) y16[(size_t)m * ldy16 + c] = (half_t)v;
+  if (y16) store_h1(y16 + (size_t)m * ldy16 + c, lo_off, v);
   if (y32) y32[(size_t)m * ldy32 + c] = v;
 }
 
@@ -131,7 +125,7 @@ __global__ void cast_add_kernel(const float* __restrict__ a, int lda, const floa
 // U8: img is uint8 [B, S, S, 3] (decoded HWC frames); the /255, -mean, /std of load_video_frames (utils/misc.py:270-276)
 // is applied here in f32, in that order, so the f16 operand is bit-identical to the one built from a normalised f32 frame
 template <bool U8>
-__global__ void im2col_patch_kernel(const void* __restrict__ img_, int B, int S, half_t* __restrict__ A) {
+__global__ void im2col_patch_kernel(const void* __restrict__ img_, int B, int S, half_t* __restrict__ A, size_t lo_off) {
   const float* img = static_cast<const float*>(img_);
   const uint8_t* img8 = static_cast<const uint8_t*>(img_);
   const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
@@ -147,7 +141,7 @@ __global__ void im2col_patch_kernel(const void* __restrict__ img_, int B, int S,
   const int win = t >> 6, in = t & 63;
   const int wpr = G / 8;
   const int y = (win / wpr) * 8 + (in >> 3), x = (win % wpr) * 8 + (in & 7);
-  half8 out;
+  half8 out, out_lo;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int k = ch * 8 + j;
@@ -161,8 +155,10 @@ __global__ void im2col_patch_kernel(const void* __restrict__ img_, int B, int S,
       }
     }
     out[j] = (half_t)v;
+    out_lo[j] = split_lo(v, out[j]);
   }
   *reinterpret_cast<half8*>(A + tok * 160 + ch * 8) = out;
+  if (lo_off) *reinterpret_cast<half8*>(A + lo_off + tok * 160 + ch * 8) = out_lo;
 }
 
 // ------------------------------------------------------------------ 2x2 max-pool inside windows
@@ -252,42 +248,42 @@ inline dim3 grid1d(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1)
 }  // namespace
 
 hipError_t layernorm_launch(const float* x, int ldx, const float* w, const float* b, float eps, int M, int C, half_t* y16,
-                            int ldy16, float* y32, int ldy32, int act, hipStream_t s) {
+                            int ldy16, float* y32, int ldy32, int act, hipStream_t s, size_t lo_off) {
   const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (!y16 || ldy16 % 4 == 0) && (!y32 || ldy32 % 4 == 0) && C <= 1280 &&
                    ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)b % 16 == 0);
   if (vec) {
     const int nv = C / 4, vpl = (nv + 63) / 64;
     const int blocks = std::min((M + 3) / 4, 256 * 16);
-#define LN_LAUNCH(V) layernorm_vec_kernel<V><<<dim3(blocks), dim3(256), 0, s>>>(x, ldx, w, b, eps, M, C, y16, ldy16, y32, ldy32, act)
+#define LN_LAUNCH(V) layernorm_vec_kernel<V><<<dim3(blocks), dim3(256), 0, s>>>(x, ldx, w, b, eps, M, C, y16, ldy16, y32, ldy32, act, lo_off)
     if (vpl <= 1) LN_LAUNCH(1);
     else if (vpl == 2) LN_LAUNCH(2);
     else if (vpl == 3) LN_LAUNCH(3);
     else LN_LAUNCH(5);
 #undef LN_LAUNCH
   } else {
-    layernorm_kernel<<<dim3((M + 3) / 4), dim3(256), 0, s>>>(x, ldx, w, b, eps, M, C, y16, ldy16, y32, ldy32, act);
+    layernorm_kernel<<<dim3((M + 3) / 4), dim3(256), 0, s>>>(x, ldx, w, b, eps, M, C, y16, ldy16, y32, ldy32, act, lo_off);
   }
   return hipGetLastError();
 }
 hipError_t cast_add_launch(const float* a, int lda, const float* b, int ldb, int bmod, float sb, int M, int C, half_t* y16,
-                           int ldy16, float* y32, int ldy32, hipStream_t s) {
+                           int ldy16, float* y32, int ldy32, hipStream_t s, size_t lo_off) {
   const bool vec = (C % 4 == 0) && (lda % 4 == 0) && (!b || ldb % 4 == 0) && (!y16 || ldy16 % 4 == 0) && (!y32 || ldy32 % 4 == 0) &&
                    ((uintptr_t)a % 16 == 0) && (!b || (uintptr_t)b % 16 == 0) && (!y16 || (uintptr_t)y16 % 8 == 0) &&
                    (!y32 || (uintptr_t)y32 % 16 == 0);
   if (vec)
-    cast_add_vec_kernel<<<grid1d((size_t)M * (C / 4)), dim3(256), 0, s>>>(a, lda, b, ldb, bmod, sb, M, C / 4, y16, ldy16, y32, ldy32);
+    cast_add_vec_kernel<<<grid1d((size_t)M * (C / 4)), dim3(256), 0, s>>>(a, lda, b, ldb, bmod, sb, M, C / 4, y16, ldy16, y32, ldy32, lo_off);
   else
-    cast_add_kernel<<<grid1d((size_t)M * C), dim3(256), 0, s>>>(a, lda, b, ldb, bmod, sb, M, C, y16, ldy16, y32, ldy32);
+    cast_add_kernel<<<grid1d((size_t)M * C), dim3(256), 0, s>>>(a, lda, b, ldb, bmod, sb, M, C, y16, ldy16, y32, ldy32, lo_off);
   return hipGetLastError();
 }
-hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStream_t s) {
+hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStream_t s, size_t lo_off) {
   const size_t total = (size_t)B * (S / 4) * (S / 4) * 20;
-  im2col_patch_kernel<false><<<grid1d(total), dim3(256), 0, s>>>(img, B, S, A);
+  im2col_patch_kernel<false><<<grid1d(total), dim3(256), 0, s>>>(img, B, S, A, lo_off);
   return hipGetLastError();
 }
-hipError_t im2col_patch_u8_launch(const uint8_t* img_hwc, int B, int S, half_t* A, hipStream_t s) {
+hipError_t im2col_patch_u8_launch(const uint8_t* img_hwc, int B, int S, half_t* A, hipStream_t s, size_t lo_off) {
   const size_t total = (size_t)B * (S / 4) * (S / 4) * 20;
-  im2col_patch_kernel<true><<<grid1d(total), dim3(256), 0, s>>>(img_hwc, B, S, A);
+  im2col_patch_kernel<true><<<grid1d(total), dim3(256), 0, s>>>(img_hwc, B, S, A, lo_off);
   return hipGetLastError();
 }
 hipError_t pool_tokens_f32_launch(const float* in, int ldin, float* out, int ldout, int nwin, int w, int C, hipStream_t s) {

@@ -25,6 +25,7 @@ struct Lin16 {            // MFMA operand: f16 weight [N, K] (nn.Linear layout),
   half_t* w = nullptr;
   float* b = nullptr;
   int N = 0, K = 0;
+  size_t lo_off = 0;           // f16x3 mode: the lo plane of w sits lo_off (= N * K) elements behind it; 0 in the f16 mode
   half_t* xs_pack = nullptr;   // same weight in the piece order of the X-stationary GEMM (Hiera stages 1-3, K <= 576)
   half_t* ks_pack = nullptr;   // ... of the accumulator-stationary GEMM (N = 576: stage-3 projection and fc2)
 };
@@ -126,6 +127,14 @@ struct sam2mi_ctx {
   float* tpos_enc = nullptr;          // [7, 64]
   float* no_obj_embed_spatial = nullptr;   // [64]
 
+  // ---- precision mode (sam2mi_config.precision).  f16x3: every f16 activation buffer below lives in ONE arena whose second
+  // half holds the lo planes, so `lo16` (elements) is the hi -> lo distance of all of them; 0 in the default f16 mode.
+  bool precise = false;
+  size_t lo16 = 0;
+  float* ws_qk32 = nullptr;    // f16x3 mode: q|k and V^T of the Hiera blocks in f32 (operands of attn_precise.hip)
+  float* ws_vT32 = nullptr;
+  float* ws_qp32 = nullptr;
+
   // ---- workspaces (sized for cfg.max_batch frames)
   float* ws_x = nullptr;        // residual stream f32
   float* ws_x2 = nullptr;       // second f32 buffer (shortcut / permute target)
@@ -207,6 +216,7 @@ int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p);              
 int run_hiera_attn(sam2mi_ctx* ctx, hipStream_t s, const HieraAttnParams& p);
 int run_mlp_fused(sam2mi_ctx* ctx, hipStream_t s, const MlpFusedParams& p, int C);     // with profiling
 int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p);
+int run_precise_attn(sam2mi_ctx* ctx, hipStream_t s, const PreciseAttnParams& p);
 GemmParams lin_params(const half_t* A, int lda, int M, const Lin16& L);            // bias + W filled, n_split = N
 
 // engine_encoder.hip

@@ -89,11 +89,11 @@ extern "C" int sam2mi_memory_attention(sam2mi_ctx* ctx, void* stream, const floa
   const int n_rope = L * 4096, Nk = n_rope + P;
   if (Nk <= 0 || (Nk + 31) / 32 * 32 > ctx->t_nk_cap) return sam2mi_set_error(ctx, __func__, "memory length out of range");
   // kin = f16(memory + memory_pos), vin = f16(memory); with N == 1 the (L,4096,1,64) tensors are [L*4096, 64] rows
-  CHK(cast_add_launch(memory, 64, memory_pos, 64, 0, 1.f, n_rope, 64, ctx->t_kin16, 64, nullptr, 0, s));
-  CHK(cast_add_launch(memory, 64, nullptr, 0, 0, 0.f, n_rope, 64, ctx->t_vin16, 64, nullptr, 0, s));
+  CHK(cast_add_launch(memory, 64, memory_pos, 64, 0, 1.f, n_rope, 64, ctx->t_kin16, 64, nullptr, 0, s, ctx->lo16));
+  CHK(cast_add_launch(memory, 64, nullptr, 0, 0, 0.f, n_rope, 64, ctx->t_vin16, 64, nullptr, 0, s, ctx->lo16));
   if (P > 0) {
-    CHK(cast_add_launch(memory_exclude, 64, memory_pos_exclude, 64, 0, 1.f, P, 64, ctx->t_kin16 + (size_t)n_rope * 64, 64, nullptr, 0, s));
-    CHK(cast_add_launch(memory_exclude, 64, nullptr, 0, 0, 0.f, P, 64, ctx->t_vin16 + (size_t)n_rope * 64, 64, nullptr, 0, s));
+    CHK(cast_add_launch(memory_exclude, 64, memory_pos_exclude, 64, 0, 1.f, P, 64, ctx->t_kin16 + (size_t)n_rope * 64, 64, nullptr, 0, s, ctx->lo16));
+    CHK(cast_add_launch(memory_exclude, 64, nullptr, 0, 0, 0.f, P, 64, ctx->t_vin16 + (size_t)n_rope * 64, 64, nullptr, 0, s, ctx->lo16));
   }
   return memattn_forward(ctx, s, curr, curr_pos, 1, &Nk, &n_rope, out);
 }
@@ -314,7 +314,7 @@ extern "C" int sam2mi_video_click(sam2mi_ctx* ctx, void* stream, int feat_slot, 
     return sam2mi_set_error(ctx, __func__, "slot out of range");
   const sam2mi_ctx::FeatSlot& f = ctx->feats[feat_slot];
   // pix_feat = feat + no_mem_embed (directly_add_no_mem_embed, sam2_base_official.py:953-957)
-  CHK(cast_add_launch(f.feat2, 256, ctx->no_mem_embed, 256, 1, 1.f, 4096, 256, nullptr, 0, ctx->t_pix, 256, s));
+  CHK(cast_add_launch(f.feat2, 256, ctx->no_mem_embed, 256, 1, 1.f, 4096, 256, nullptr, 0, ctx->t_pix, 256, s, ctx->lo16));
   int T = 0;
   CHKI(build_tokens(ctx, s, coords, labels, 1, Np, T));
   DecoderIn in = one_image_in(ctx, f);
@@ -371,7 +371,7 @@ extern "C" int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot
   if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size()) return sam2mi_set_error(ctx, __func__, "slot out of range");
   if (N < 1) return sam2mi_set_error(ctx, __func__, "no prompts");
   const sam2mi_ctx::FeatSlot& f = ctx->feats[feat_slot];
-  CHK(cast_add_launch(f.feat2, 256, ctx->no_mem_embed, 256, 1, 1.f, 4096, 256, nullptr, 0, ctx->t_pix, 256, s));
+  CHK(cast_add_launch(f.feat2, 256, ctx->no_mem_embed, 256, 1, 1.f, 4096, 256, nullptr, 0, ctx->t_pix, 256, s, ctx->lo16));
   // N independent prompts on ONE image (repeat_image, sam2_image_predictor.py:564-579): batched through the decoder
   for (int n0 = 0; n0 < N; n0 += DEC_MAX_N) {
     const int nb = std::min(DEC_MAX_N, N - n0);
@@ -446,6 +446,7 @@ static int assemble_object_memory(sam2mi_ctx* ctx, hipStream_t s, const sam2mi_m
   }
   ma.pos = ctx->mem_pos; ma.ptr_tok = ptr_tok; ma.ptr_pos = ptr_pos; ma.P = P;
   ma.kin = ctx->t_kin16 + (size_t)n * ctx->t_nk_cap * 64; ma.vin = ctx->t_vin16 + (size_t)n * ctx->t_nk_cap * 64;
+  ma.lo_off = ctx->lo16;
   CHK(mem_assemble_launch(ma, s));
   Nk = L * 4096 + P;
   n_rope = L * 4096;

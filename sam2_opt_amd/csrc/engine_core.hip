@@ -91,7 +91,13 @@ static bool ks_eligible(const sam2mi_ctx* ctx, const GemmParams& p) {
   return ctx->use_ks && p.ks_pack && p.tile_hint == 0 && p.M >= 16384 && gemm_ks_supported(p.N, p.K) && p.act == ACT_NONE &&
          !p.col_scale && p.rope_cols == 0 && p.res_mod == 0 && p.out32 && !p.out16 && !p.outT16 && !p.outT32 && p.n_split >= p.N && p.bias;
 }
-int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p) {
+int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p_in) {
+  GemmParams p = p_in;
+  if (ctx->precise) {            // f16x3: split operands (activations: arena lo plane; weights: packed [hi | lo], or an arena buffer)
+    if (!p.a_lo_off) p.a_lo_off = ctx->lo16;
+    if (!p.w_lo_off) p.w_lo_off = ctx->lo16;
+    p.out_lo_off = (p.out16 || p.outT16) ? ctx->lo16 : 0;
+  }
   if (ks_eligible(ctx, p)) {
     GemmKsParams k{p.A, p.lda, p.ks_pack, p.bias, p.res, p.ldres, p.out32, p.ld32, p.M, p.K};
     hipEvent_t e0, e1;
@@ -135,6 +141,14 @@ int run_hiera_attn(sam2mi_ctx* ctx, hipStream_t s, const HieraAttnParams& p) {
   if (ctx->prof_on) prof_end(ctx->prof_attn, s, e0, e1, 4.0 * p.num_groups * (double)p.GQ * nk_vis * 72.0 * p.heads);
   return 0;
 }
+int run_precise_attn(sam2mi_ctx* ctx, hipStream_t s, const PreciseAttnParams& p) {
+  hipEvent_t e0, e1;
+  if (ctx->prof_on) prof_begin(ctx, ctx->prof_attn, s, e0, e1);
+  CHK(precise_attn_launch(p, s));
+  const double nk_vis = (p.wq >= p.GQ) ? p.GK : p.wk;
+  if (ctx->prof_on) prof_end(ctx->prof_attn, s, e0, e1, 4.0 * p.num_groups * (double)p.GQ * nk_vis * 72.0 * p.heads);
+  return 0;
+}
 int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p) {
   hipEvent_t e0, e1;
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_attn, s, e0, e1);
@@ -146,6 +160,7 @@ int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p) {
 GemmParams lin_params(const half_t* A, int lda, int M, const Lin16& L) {
   GemmParams p = gemm_params_zero();
   p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.K; p.M = M; p.N = L.N; p.K = L.K; p.bias = L.b; p.n_split = L.N; p.xs_pack = L.xs_pack; p.ks_pack = L.ks_pack;
+  p.w_lo_off = L.lo_off;
   return p;
 }
 
@@ -178,8 +193,13 @@ struct Packer {
   }
   Lin16 lin16_raw(const std::vector<float>& W, const std::vector<float>& b, int N, int K) {
     Lin16 l;
-    std::vector<half_t> h((size_t)N * K);
-    for (size_t i = 0; i < h.size(); ++i) h[i] = (half_t)W[i];
+    const size_t n = (size_t)N * K;
+    std::vector<half_t> h(ctx->precise ? 2 * n : n);
+    for (size_t i = 0; i < n; ++i) {
+      h[i] = (half_t)W[i];
+      if (ctx->precise) h[n + i] = (half_t)((W[i] - (float)h[i]) * 2048.0f);      // lo plane (common.h: SPLIT_SCALE)
+    }
+    if (ctx->precise) l.lo_off = n;
     l.w = dupload(ctx, h);
     l.b = dupload(ctx, b);
     l.N = N;
@@ -282,7 +302,7 @@ std::vector<float> sine_pe_nchw(int H, int W, int F) {
 }
 }  // namespace
 
-extern "C" int sam2mi_abi_version(void) { return 1; }
+extern "C" int sam2mi_abi_version(void) { return 2; }      // 2: sam2mi_config.precision
 
 extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   if (!cfg || !out) return sam2mi_set_error(nullptr, "sam2mi_create", "null argument");
@@ -294,9 +314,17 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   if (ctx->cfg.max_batch <= 0) ctx->cfg.max_batch = 1;
   if (ctx->cfg.bank_slots <= 0) ctx->cfg.bank_slots = 64;
   if (ctx->cfg.feat_slots <= 0) ctx->cfg.feat_slots = 16;
-  ctx->use_fused_mlp = getenv("SAM2MI_NO_FUSED_MLP") == nullptr;
-  ctx->use_xs = getenv("SAM2MI_NO_XS") == nullptr;
-  ctx->use_ks = getenv("SAM2MI_KS") != nullptr;     // experimental (no end-to-end gain over the tiled kernel on fc2): opt-in
+  if (ctx->cfg.precision != SAM2MI_PRECISION_F16 && ctx->cfg.precision != SAM2MI_PRECISION_F16X3) {
+    sam2mi_set_error(nullptr, "sam2mi_create", "unknown precision (0: f16, 1: f16x3)");
+    delete ctx;
+    return 1;
+  }
+  ctx->precise = ctx->cfg.precision == SAM2MI_PRECISION_F16X3;
+  // the X-stationary / fused-MLP / accumulator-stationary kernels take plain f16 operands: the f16x3 mode runs every linear
+  // on the split-operand instantiation of the tiled kernel (gemm2.hip)
+  ctx->use_fused_mlp = !ctx->precise && getenv("SAM2MI_NO_FUSED_MLP") == nullptr;
+  ctx->use_xs = !ctx->precise && getenv("SAM2MI_NO_XS") == nullptr;
+  ctx->use_ks = !ctx->precise && getenv("SAM2MI_KS") != nullptr;     // experimental (no end-to-end gain over the tiled kernel on fc2): opt-in
   hipError_t e = gemm_init();
   if (e == hipSuccess) e = flash256_init();
   if (e == hipSuccess) e = mlp_fused_init();
@@ -441,16 +469,16 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
       b.fc1 = pk.lin16(p + "mlp.layers.0");
       b.fc2 = pk.lin16(p + "mlp.layers.1");
       for (Lin16* L : {&b.qkv, &b.fc1}) {       // stages 1-3: QKV and fc1 also in the X-stationary kernel's piece order (the projection, N = K, is not faster there)
-        if (!pk.ok || !L->w || !gemm_xs_supported(L->N, L->K) || (L == &b.fc1 && mlp_fused_supported(b.dim_out))) continue;
+        if (!pk.ok || ctx->precise || !L->w || !gemm_xs_supported(L->N, L->K) || (L == &b.fc1 && mlp_fused_supported(b.dim_out))) continue;
         L->xs_pack = (half_t*)dalloc(ctx, gemm_xs_pack_bytes(L->N, L->K));
         if (!L->xs_pack || gemm_xs_pack(L->w, L->N, L->K, L->K, L->xs_pack, nullptr) != hipSuccess) pk.ok = false;
       }
       for (Lin16* L : {&b.fc2}) {       // stage 3 (N = 576, K = 2304): fc2 in the accumulator-stationary kernel's order (the projection, K = 576, is faster tiled)
-        if (!pk.ok || !L->w || !gemm_ks_supported(L->N, L->K)) continue;
+        if (!pk.ok || ctx->precise || !L->w || !gemm_ks_supported(L->N, L->K)) continue;
         L->ks_pack = (half_t*)dalloc(ctx, gemm_ks_pack_bytes(L->N, L->K));
         if (!L->ks_pack || gemm_ks_pack(L->w, L->N, L->K, L->K, L->ks_pack, nullptr) != hipSuccess) pk.ok = false;
       }
-      if (pk.ok && mlp_fused_supported(b.dim_out)) {     // stages 1-2: weights also in the fused MLP kernel's piece order
+      if (pk.ok && !ctx->precise && mlp_fused_supported(b.dim_out)) {     // stages 1-2: weights also in the fused MLP kernel's piece order
         b.mlp_pack = (half_t*)dalloc(ctx, mlp_fused_pack_bytes(b.dim_out));
         if (!b.mlp_pack || mlp_fused_pack(b.fc1.w, b.fc2.w, b.dim_out, b.mlp_pack, nullptr) != hipSuccess) pk.ok = false;
       }
@@ -710,32 +738,41 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
     ptr = (type*)dalloc(ctx, (size_t)(count) * sizeof(type));                       \
     if (!ptr) return sam2mi_set_error(ctx, "hipMalloc", #ptr);                      \
   } while (0)
+  // every f16 activation buffer comes out of ONE arena (256-B aligned pieces); the f16x3 mode doubles it and keeps the lo
+  // plane of each buffer `ctx->lo16` elements behind its hi plane (one offset for all of them)
+  std::vector<std::pair<half_t**, size_t>> arena16;
+  size_t arena_elems = 0;
+#define ARENA16(ptr, count)                                                         \
+  do {                                                                              \
+    arena16.push_back({&(ptr), arena_elems});                                       \
+    arena_elems += ((size_t)(count) + 127) / 128 * 128;                             \
+  } while (0)
   ALLOC(ctx->ws_x, float, T0 * E);
   ALLOC(ctx->ws_x2, float, T0 * 2 * E);              // shortcut projection output (unpooled, 2C)
-  ALLOC(ctx->ws_a16, half_t, T0 * 160);              // LN output (<= 144 ch) or im2col patches (160)
-  ALLOC(ctx->ws_qk16, half_t, T0 * 4 * E);           // [M, 2*Cout], Cout up to 2E at stage-1 tokens (block 2)
-  ALLOC(ctx->ws_vT16, half_t, T0 * 2 * E);
-  ALLOC(ctx->ws_att16, half_t, T0 * E);
-  ALLOC(ctx->ws_h16, half_t, T0 * 4 * E);
-  ALLOC(ctx->ws_qp16, half_t, T0 / 4 * 2 * E);
+  ARENA16(ctx->ws_a16, T0 * 160);              // LN output (<= 144 ch) or im2col patches (160)
+  ARENA16(ctx->ws_qk16, T0 * 4 * E);           // [M, 2*Cout], Cout up to 2E at stage-1 tokens (block 2)
+  ARENA16(ctx->ws_vT16, T0 * 2 * E);
+  ARENA16(ctx->ws_att16, T0 * E);
+  ARENA16(ctx->ws_h16, T0 * 4 * E);
+  ARENA16(ctx->ws_qp16, T0 / 4 * 2 * E);
   for (int l = 0; l < 4; ++l) ALLOC(ctx->ws_lat[l], float, (T0 >> (2 * l)) * 256);
-  ALLOC(ctx->ws_lat16, half_t, T0 * 256);
+  ARENA16(ctx->ws_lat16, T0 * 256);
   ALLOC(ctx->ws_small, float, T0 * 64);
 
   // tracking (B = 1)
   const int NKCAP = 7 * 4096 + 64 * 4 + 4096;         // generous: many conditioning frames are rejected above this
   ctx->t_nk_cap = NKCAP;
   ALLOC(ctx->t_x, float, (size_t)TRACK_MAX_N * 4096 * 256);
-  ALLOC(ctx->t_h16, half_t, (size_t)TRACK_MAX_N * 4096 * 256);
-  ALLOC(ctx->t_qk16, half_t, (size_t)TRACK_MAX_N * 4096 * 512);
-  ALLOC(ctx->t_vT16, half_t, (size_t)TRACK_MAX_N * 256 * 4096);
-  ALLOC(ctx->t_o16, half_t, (size_t)TRACK_MAX_N * 4096 * 256);
-  ALLOC(ctx->t_q16, half_t, (size_t)TRACK_MAX_N * 4096 * 256);
-  ALLOC(ctx->t_ff16, half_t, (size_t)TRACK_MAX_N * 4096 * 2048);
-  ALLOC(ctx->t_kin16, half_t, (size_t)TRACK_MAX_N * NKCAP * 64);
-  ALLOC(ctx->t_vin16, half_t, (size_t)TRACK_MAX_N * NKCAP * 64);
-  ALLOC(ctx->t_kall16, half_t, (size_t)TRACK_MAX_N * NKCAP * 1024);
-  ALLOC(ctx->t_vTall16, half_t, (size_t)TRACK_MAX_N * 1024 * NKCAP);
+  ARENA16(ctx->t_h16, (size_t)TRACK_MAX_N * 4096 * 256);
+  ARENA16(ctx->t_qk16, (size_t)TRACK_MAX_N * 4096 * 512);
+  ARENA16(ctx->t_vT16, (size_t)TRACK_MAX_N * 256 * 4096);
+  ARENA16(ctx->t_o16, (size_t)TRACK_MAX_N * 4096 * 256);
+  ARENA16(ctx->t_q16, (size_t)TRACK_MAX_N * 4096 * 256);
+  ARENA16(ctx->t_ff16, (size_t)TRACK_MAX_N * 4096 * 2048);
+  ARENA16(ctx->t_kin16, (size_t)TRACK_MAX_N * NKCAP * 64);
+  ARENA16(ctx->t_vin16, (size_t)TRACK_MAX_N * NKCAP * 64);
+  ARENA16(ctx->t_kall16, (size_t)TRACK_MAX_N * NKCAP * 1024);
+  ARENA16(ctx->t_vTall16, (size_t)TRACK_MAX_N * 1024 * NKCAP);
   ALLOC(ctx->t_opart, float, (size_t)16 * 4096 * 256);
   ALLOC(ctx->d_fill_tmp, float, (size_t)65536);
   ALLOC(ctx->d_mask256, float, (size_t)65536);
@@ -748,8 +785,8 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ALLOC(ctx->t_pix, float, (size_t)TRACK_MAX_N * 4096 * 256);
   // decoder
   ALLOC(ctx->d_keys, float, (size_t)DEC_MAX_N * 4096 * 256);
-  ALLOC(ctx->d_keys16, half_t, (size_t)DEC_MAX_N * 4096 * 256);
-  ALLOC(ctx->d_kpe16, half_t, (size_t)DEC_MAX_N * 4096 * 256);
+  ARENA16(ctx->d_keys16, (size_t)DEC_MAX_N * 4096 * 256);
+  ARENA16(ctx->d_kpe16, (size_t)DEC_MAX_N * 4096 * 256);
   ALLOC(ctx->d_tok, float, (size_t)DEC_MAX_N * 64 * 256);
   ALLOC(ctx->d_tokpe, float, (size_t)DEC_MAX_N * 64 * 256);
   ALLOC(ctx->d_t1, float, (size_t)DEC_MAX_N * 64 * 2048);
@@ -759,14 +796,14 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ALLOC(ctx->d_big1, float, (size_t)DEC_MAX_N * 4096 * 256);
   ALLOC(ctx->d_big2, float, (size_t)DEC_MAX_N * 4096 * 256);
   ALLOC(ctx->d_big3, float, (size_t)DEC_MAX_N * 4096 * 256);
-  ALLOC(ctx->d_big16, half_t, (size_t)DEC_MAX_N * 4096 * 256);
+  ARENA16(ctx->d_big16, (size_t)DEC_MAX_N * 4096 * 256);
   ALLOC(ctx->d_tokens_in, float, (size_t)DEC_MAX_N * 64 * 256);
   ALLOC(ctx->d_sparse, float, (size_t)DEC_MAX_N * 64 * 256);
-  ALLOC(ctx->d_up1_16, half_t, (size_t)DEC_MAX_N * 16384 * 64);
-  ALLOC(ctx->d_up2_16, half_t, (size_t)DEC_MAX_N * 65536 * 32);
+  ARENA16(ctx->d_up1_16, (size_t)DEC_MAX_N * 16384 * 64);
+  ARENA16(ctx->d_up2_16, (size_t)DEC_MAX_N * 65536 * 32);
   ALLOC(ctx->d_g, float, (size_t)DEC_MAX_N * 16384 * 128);
   ALLOC(ctx->d_hyper, float, (size_t)DEC_MAX_N * 4 * 32);
-  ALLOC(ctx->d_hyper16, half_t, (size_t)(DEC_MAX_N * 4 + 32) * 32);
+  ARENA16(ctx->d_hyper16, (size_t)(DEC_MAX_N * 4 + 32) * 32);
   ALLOC(ctx->d_masks, float, (size_t)DEC_MAX_N * 4 * 65536);
   ALLOC(ctx->d_iou, float, DEC_MAX_N * 4 + 8);
   ALLOC(ctx->d_obj, float, DEC_MAX_N + 8);
@@ -784,18 +821,18 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ALLOC(ctx->m_mask, float, 1024 * 1024);
   ALLOC(ctx->m_c1, float, 512 * 512 * 4);
   ALLOC(ctx->m_c2, float, 256 * 256 * 16);
-  ALLOC(ctx->m_c2_16, half_t, 256 * 256 * 16);
-  ALLOC(ctx->m_c3_16, half_t, 128 * 128 * 64);
-  ALLOC(ctx->m_col16, half_t, 4096 * 576);
+  ARENA16(ctx->m_c2_16, 256 * 256 * 16);
+  ARENA16(ctx->m_c3_16, 128 * 128 * 64);
+  ARENA16(ctx->m_col16, 4096 * 576);
   ALLOC(ctx->m_c4, float, 4096 * 256);
-  ALLOC(ctx->m_c4_16, half_t, 4096 * 256);
+  ARENA16(ctx->m_c4_16, 4096 * 256);
   ALLOC(ctx->m_emb, float, 4096 * 256);
   ALLOC(ctx->m_x, float, 4096 * 256);
   ALLOC(ctx->m_dw, float, 4096 * 256);
-  ALLOC(ctx->m_ln16, half_t, 4096 * 256);
-  ALLOC(ctx->m_h16, half_t, 4096 * 1024);
+  ARENA16(ctx->m_ln16, 4096 * 256);
+  ARENA16(ctx->m_h16, 4096 * 1024);
   ALLOC(ctx->m_out, float, 4096 * 64);
-  ALLOC(ctx->m_pix16, half_t, 4096 * 256);
+  ARENA16(ctx->m_pix16, 4096 * 256);
   // plug scratch
   ALLOC(ctx->p_a, float, (size_t)DEC_MAX_N * 65536 * 32);
   ALLOC(ctx->p_b, float, (size_t)65536 * 32);
@@ -815,6 +852,18 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
     ALLOC(b.obj_score, float, 4);
     ALLOC(b.low_mask, float, 65536);
   }
+  {
+    half_t* base = (half_t*)dalloc(ctx, arena_elems * sizeof(half_t) * (ctx->precise ? 2 : 1));
+    if (!base) return sam2mi_set_error(ctx, "hipMalloc", "f16 activation arena");
+    for (auto& a : arena16) *a.first = base + a.second;
+    ctx->lo16 = ctx->precise ? arena_elems : 0;
+  }
+  if (ctx->precise) {
+    ALLOC(ctx->ws_qk32, float, T0 * 4 * E);
+    ALLOC(ctx->ws_vT32, float, T0 * 2 * E);
+    ALLOC(ctx->ws_qp32, float, T0 / 4 * 2 * E);
+  }
 #undef ALLOC
+#undef ARENA16
   return 0;
 }

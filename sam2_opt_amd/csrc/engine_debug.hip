@@ -24,6 +24,16 @@ __global__ void f16_to_f32_kernel(const half_t* __restrict__ in, float* __restri
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (float)in[i];
 }
+__global__ void split_to_f32_kernel(const half_t* __restrict__ in, size_t lo_off, float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)in[i] + (float)in[i + lo_off] * SPLIT_INV;
+}
+__global__ void transpose_f32_scale_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc, int ldo) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)R * Cc) return;
+  const int r = (int)(i / Cc), c = (int)(i % Cc);
+  out[(size_t)c * ldo + r] = in[i];
+}
 }  // namespace
 
 extern "C" int sam2mi_debug_gemm(sam2mi_ctx* ctx, void* stream, const float* A, const float* W, const float* bias, int M, int N, int K,
@@ -31,12 +41,15 @@ extern "C" int sam2mi_debug_gemm(sam2mi_ctx* ctx, void* stream, const float* A, 
   if (!ctx) return 1;
   hipStream_t s = (hipStream_t)stream;
   Tmp t;
-  half_t* a16 = t.get<half_t>((size_t)M * K);
-  half_t* w16 = t.get<half_t>((size_t)N * K);
+  const bool split = ctx->precise;       // f16x3 context: operands as hi + lo planes, lo right behind hi
+  const size_t alo = split ? (size_t)M * K : 0, wlo = split ? (size_t)N * K : 0;
+  half_t* a16 = t.get<half_t>((size_t)M * K * (split ? 2 : 1));
+  half_t* w16 = t.get<half_t>((size_t)N * K * (split ? 2 : 1));
   if (!a16 || !w16) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
-  CHK(cast_add_launch(A, K, nullptr, 0, 0, 0.f, M, K, a16, K, nullptr, 0, s));
-  CHK(cast_add_launch(W, K, nullptr, 0, 0, 0.f, N, K, w16, K, nullptr, 0, s));
+  CHK(cast_add_launch(A, K, nullptr, 0, 0, 0.f, M, K, a16, K, nullptr, 0, s, alo));
+  CHK(cast_add_launch(W, K, nullptr, 0, 0, 0.f, N, K, w16, K, nullptr, 0, s, wlo));
   GemmParams p = gemm_params_zero();
+  p.a_lo_off = alo; p.w_lo_off = wlo;
   p.A = a16; p.lda = K; p.W = w16; p.ldw = K; p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act & 0xFF; p.n_split = N;
   p.tile_hint = act >> 8;            // tests: force a tile / kernel variant
   p.res = residual; p.ldres = N; p.out32 = out; p.ld32 = N;
@@ -72,6 +85,24 @@ extern "C" int sam2mi_debug_hiera_attention(sam2mi_ctx* ctx, void* stream, const
   hipStream_t s = (hipStream_t)stream;
   const int C = heads * 72, Mq = groups * GQ, Mk = groups * GK;
   Tmp t;
+  if (ctx->precise) {                    // f16x3 context: the split-operand kernel on f32 inputs
+    float* q32 = t.get<float>((size_t)Mq * C);
+    float* vT32 = t.get<float>((size_t)C * Mk);
+    half_t* o = t.get<half_t>((size_t)Mq * C * 2);
+    if (!q32 || !vT32 || !o) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+    CHK(cast_add_launch(q, C, q, C, 0, 1.4426950408889634f / sqrtf(72.f) - 1.f, Mq, C, nullptr, 0, q32, C, s));   // pre-scaled q
+    transpose_f32_scale_kernel<<<dim3((unsigned)(((size_t)Mk * C + 255) / 256)), dim3(256), 0, s>>>(v, vT32, Mk, C, Mk);
+    CHK(hipGetLastError());
+    PreciseAttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.q = q32; a.ldq = C; a.k = k; a.ldk = C; a.vT = vT32; a.ldvT = Mk; a.o = o; a.ldo = C; a.o_lo_off = (size_t)Mq * C; a.heads = heads;
+    a.GQ = GQ; a.GK = GK; a.wq = wq; a.wk = wk; a.num_groups = groups;
+    CHKI(run_precise_attn(ctx, s, a));
+    split_to_f32_kernel<<<dim3((unsigned)(((size_t)Mq * C + 255) / 256)), dim3(256), 0, s>>>(o, (size_t)Mq * C, out, (size_t)Mq * C);
+    CHK(hipGetLastError());
+    CHK(hipStreamSynchronize(s));
+    return 0;
+  }
   half_t* q16 = t.get<half_t>((size_t)Mq * C);
   half_t* k16 = t.get<half_t>((size_t)Mk * C);
   half_t* vT = t.get<half_t>((size_t)C * Mk);

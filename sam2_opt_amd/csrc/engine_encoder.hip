@@ -17,7 +17,7 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   const int C = b.dim, Co = b.dim_out;
   float* x = ctx->ws_x;
   // 1. LN1
-  CHK(layernorm_launch(x, C, b.n1.w, b.n1.b, 1e-6f, M, C, ctx->ws_a16, C, nullptr, 0, 0, s));
+  CHK(layernorm_launch(x, C, b.n1.w, b.n1.b, 1e-6f, M, C, ctx->ws_a16, C, nullptr, 0, 0, s, ctx->lo16));
   int Mq = M;
   float* xres = x;           // residual target of the attention projection
   if (b.q_pool) {
@@ -34,11 +34,41 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
     p.n_split = 2 * Co;
     p.col_scale = b.qscale;                 // q pre-scaled (f32, before the f16 rounding) for the exp2-domain softmax
     p.xs_scale_cols = Co;                   // k / v columns have scale 1
-    p.out16 = ctx->ws_qk16; p.ld16 = 2 * Co;
-    p.outT16 = ctx->ws_vT16; p.ldT16 = M;
+    if (ctx->precise) {                     // f16x3 mode: the attention kernel takes f32 q / k / V^T and splits them itself
+      p.out32 = ctx->ws_qk32; p.ld32 = 2 * Co;
+      p.outT32 = ctx->ws_vT32; p.ldT32 = M;
+    } else {
+      p.out16 = ctx->ws_qk16; p.ld16 = 2 * Co;
+      p.outT16 = ctx->ws_vT16; p.ldT16 = M;
+    }
     CHKI(run_gemm(ctx, s, p));
   }
   // 3. attention
+  if (ctx->precise) {
+    PreciseAttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.k = ctx->ws_qk32 + Co; a.ldk = 2 * Co;
+    a.vT = ctx->ws_vT32; a.ldvT = M;
+    a.o = ctx->ws_att16; a.ldo = Co; a.o_lo_off = ctx->lo16;
+    a.heads = b.heads;
+    const int win = (b.window > 0) ? wcur : 0;
+    if (!b.q_pool) {
+      a.q = ctx->ws_qk32; a.ldq = 2 * Co;
+      if (win == 0) { a.GQ = a.GK = H * W; a.wq = a.GQ; a.wk = a.GK; a.num_groups = B; }
+      else {
+        const int n = win * win;
+        if (n >= 32) { a.GQ = a.GK = n; a.wq = a.wk = n; a.num_groups = M / n; }
+        else { a.GQ = a.GK = 32; a.wq = a.wk = n; a.num_groups = M / 32; }
+      }
+    } else {
+      CHK(pool_tokens_f32_launch(ctx->ws_qk32, 2 * Co, ctx->ws_qp32, Co, M / (wcur * wcur), wcur, Co, s));
+      a.q = ctx->ws_qp32; a.ldq = Co;
+      const int nk = wcur * wcur, nq = nk / 4;
+      if (nq >= 32) { a.GQ = nq; a.GK = nk; a.wq = nq; a.wk = nk; a.num_groups = M / nk; }
+      else { const int pack = 32 / nq; a.GQ = 32; a.GK = pack * nk; a.wq = nq; a.wk = nk; a.num_groups = M / a.GK; }
+    }
+    CHKI(run_precise_attn(ctx, s, a));
+  } else {
   HieraAttnParams a;
   memset(&a, 0, sizeof(a));
   a.k = ctx->ws_qk16 + Co; a.ldk = 2 * Co;
@@ -64,6 +94,7 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
     else { const int pack = 32 / nq; a.GQ = 32; a.GK = pack * nk; a.wq = nq; a.wk = nk; a.num_groups = M / a.GK; }
   }
   CHKI(run_hiera_attn(ctx, s, a));
+  }
   // 4. output projection + residual
   {
     GemmParams p = lin_params(ctx->ws_att16, Co, Mq, b.proj);
@@ -72,7 +103,7 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   }
   if (b.q_pool) { H /= 2; W /= 2; wcur /= 2; }
   // 5-7. MLP
-  CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s));
+  CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s, ctx->lo16));
   if (ctx->use_fused_mlp && b.mlp_pack) {
     // stages 1-2: fc1 -> GELU -> fc2 -> +x in one kernel, the 4C-wide hidden never leaves the CU (mlp_fused.hip)
     MlpFusedParams m{ctx->ws_a16, Co, b.mlp_pack, b.fc1.b, b.fc2.b, x, Co, Mq};
@@ -99,8 +130,8 @@ static int trunk_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, const
   const int G = c.image_size / 4, E = c.embed_dim;
   int H = G, W = G, wcur = 8;
   // patch embed (conv 7x7 s4 p3 as im2col GEMM) + position table, written in window-major order
-  if (img_u8) CHK(im2col_patch_u8_launch(img_u8, B, c.image_size, ctx->ws_a16, s));
-  else CHK(im2col_patch_launch(img, B, c.image_size, ctx->ws_a16, s));
+  if (img_u8) CHK(im2col_patch_u8_launch(img_u8, B, c.image_size, ctx->ws_a16, s, ctx->lo16));
+  else CHK(im2col_patch_launch(img, B, c.image_size, ctx->ws_a16, s, ctx->lo16));
   {
     GemmParams p = lin_params(ctx->ws_a16, 160, B * G * G, ctx->patch);
     p.res = ctx->pos_tab; p.ldres = E; p.res_mod = G * G;
@@ -123,7 +154,7 @@ static int trunk_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, const
     if (b.stage_end) {
       // lateral 1x1 conv of the FPN on this stage's output (image_encoder.py:113-114)
       const int M = B * H * W;
-      CHK(cast_add_launch(ctx->ws_x, b.dim_out, nullptr, 0, 0, 0.f, M, b.dim_out, ctx->ws_a16, b.dim_out, nullptr, 0, s));
+      CHK(cast_add_launch(ctx->ws_x, b.dim_out, nullptr, 0, 0, 0.f, M, b.dim_out, ctx->ws_a16, b.dim_out, nullptr, 0, s, ctx->lo16));
       GemmParams p = lin_params(ctx->ws_a16, b.dim_out, M, ctx->neck[level]);
       p.out32 = ctx->ws_lat[level]; p.ld32 = 256;
       CHKI(run_gemm(ctx, s, p));
@@ -152,7 +183,7 @@ int encoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, con
   // level 1 (128x128): conv_s1 (256 -> 64) on the lateral, then to row-major
   {
     const int M = B * (G / 2) * (G / 2);
-    CHK(cast_add_launch(ctx->ws_lat[1], 256, nullptr, 0, 0, 0.f, M, 256, ctx->ws_lat16, 256, nullptr, 0, s));
+    CHK(cast_add_launch(ctx->ws_lat[1], 256, nullptr, 0, 0, 0.f, M, 256, ctx->ws_lat16, 256, nullptr, 0, s, ctx->lo16));
     GemmParams p = lin_params(ctx->ws_lat16, 256, M, ctx->conv_s1);
     p.out32 = ctx->ws_small; p.ld32 = 64;
     CHKI(run_gemm(ctx, s, p));
@@ -164,7 +195,7 @@ int encoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, con
   // level 0 (256x256): conv_s0 (256 -> 32)
   {
     const int M = B * G * G;
-    CHK(cast_add_launch(ctx->ws_lat[0], 256, nullptr, 0, 0, 0.f, M, 256, ctx->ws_lat16, 256, nullptr, 0, s));
+    CHK(cast_add_launch(ctx->ws_lat[0], 256, nullptr, 0, 0, 0.f, M, 256, ctx->ws_lat16, 256, nullptr, 0, s, ctx->lo16));
     GemmParams p = lin_params(ctx->ws_lat16, 256, M, ctx->conv_s0);
     p.out32 = ctx->ws_small; p.ld32 = 32;
     CHKI(run_gemm(ctx, s, p));

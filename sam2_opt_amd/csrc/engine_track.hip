@@ -22,7 +22,7 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
   for (int n = 0; n < N; ++n) {
     if (Nk[n] <= 0 || ceil32(Nk[n]) > ctx->t_nk_cap) return sam2mi_set_error(ctx, "memattn_forward", "memory length out of range");
     // x = curr + 0.1 * curr_pos   (pos_enc_at_input, :319-321)
-    CHK(cast_add_launch(curr, C, curr_pos, C, 0, 0.1f, S, C, nullptr, 0, x + (size_t)n * S * C, C, s));
+    CHK(cast_add_launch(curr, C, curr_pos, C, 0, 0.1f, S, C, nullptr, 0, x + (size_t)n * S * C, C, s, ctx->lo16));
     // K / V of the memory for all 4 layers at once: K_all [Nk, 4*256] (RoPE on rows < n_rope), V^T_all [4*256, NkP]
     GemmParams p = lin_params(ctx->t_kin16 + n * cap * 64, 64, Nk[n], ctx->cross_k_all);
     p.out16 = ctx->t_kall16 + n * cap * 1024; p.ld16 = 1024;
@@ -35,7 +35,7 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
   for (int l = 0; l < 4; ++l) {
     const MemAttnLayerW& L = ctx->mal[l];
     // ---- self attention
-    CHK(layernorm_launch(x, C, L.n1.w, L.n1.b, 1e-5f, M, C, ctx->t_h16, C, nullptr, 0, 0, s));
+    CHK(layernorm_launch(x, C, L.n1.w, L.n1.b, 1e-5f, M, C, ctx->t_h16, C, nullptr, 0, 0, s, ctx->lo16));
     {
       GemmParams p = lin_params(ctx->t_h16, C, M, L.self_qkv);
       p.n_split = 512; p.out16 = ctx->t_qk16; p.ld16 = 512; p.outT16 = ctx->t_vT16; p.ldT16 = M;
@@ -48,7 +48,7 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
       memset(&f, 0, sizeof(f));
       f.q = ctx->t_qk16 + (size_t)n * S * 512; f.ldq = 512; f.k = f.q + 256; f.ldk = 512; f.vT = ctx->t_vT16 + (size_t)n * S; f.ldvT = M;
       f.Nq = S; f.Nk = S; f.splits = flash256_pick_splits(S, S); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
-      f.out = ctx->t_o16 + (size_t)n * S * C; f.ldout = C; f.scale_log2e = LOG2E / 16.f;
+      f.out = ctx->t_o16 + (size_t)n * S * C; f.ldout = C; f.scale_log2e = LOG2E / 16.f; f.out_lo_off = ctx->lo16;
       CHKI(run_flash256(ctx, s, f));
     }
     {
@@ -57,7 +57,7 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
       CHKI(run_gemm(ctx, s, p));
     }
     // ---- cross attention to the memory bank
-    CHK(layernorm_launch(x, C, L.n2.w, L.n2.b, 1e-5f, M, C, ctx->t_h16, C, nullptr, 0, 0, s));
+    CHK(layernorm_launch(x, C, L.n2.w, L.n2.b, 1e-5f, M, C, ctx->t_h16, C, nullptr, 0, 0, s, ctx->lo16));
     {
       GemmParams p = lin_params(ctx->t_h16, C, M, L.cross_q);
       p.out16 = ctx->t_q16; p.ld16 = C; p.col_scale = ctx->qs_cross;
@@ -71,7 +71,7 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
       f.q = ctx->t_q16 + (size_t)n * S * C; f.ldq = C; f.k = ctx->t_kall16 + n * cap * 1024 + l * 256; f.ldk = 1024;
       f.vT = ctx->t_vTall16 + n * cap * 1024 + (size_t)l * 256 * NkP; f.ldvT = NkP;
       f.Nq = S; f.Nk = Nk[n]; f.splits = flash256_pick_splits(S, Nk[n]); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
-      f.out = ctx->t_o16 + (size_t)n * S * C; f.ldout = C; f.scale_log2e = LOG2E / 16.f;
+      f.out = ctx->t_o16 + (size_t)n * S * C; f.ldout = C; f.scale_log2e = LOG2E / 16.f; f.out_lo_off = ctx->lo16;
       CHKI(run_flash256(ctx, s, f));
     }
     {
@@ -80,7 +80,7 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
       CHKI(run_gemm(ctx, s, p));
     }
     // ---- FFN
-    CHK(layernorm_launch(x, C, L.n3.w, L.n3.b, 1e-5f, M, C, ctx->t_h16, C, nullptr, 0, 0, s));
+    CHK(layernorm_launch(x, C, L.n3.w, L.n3.b, 1e-5f, M, C, ctx->t_h16, C, nullptr, 0, 0, s, ctx->lo16));
     {
       GemmParams p = lin_params(ctx->t_h16, C, M, L.lin1);
       p.act = ACT_RELU; p.out16 = ctx->t_ff16; p.ld16 = 2048;
@@ -90,7 +90,7 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
       CHKI(run_gemm(ctx, s, q));
     }
   }
-  CHK(layernorm_launch(x, C, ctx->ma_norm.w, ctx->ma_norm.b, 1e-5f, M, C, nullptr, 0, out32, C, 0, s));
+  CHK(layernorm_launch(x, C, ctx->ma_norm.w, ctx->ma_norm.b, 1e-5f, M, C, nullptr, 0, out32, C, 0, s, ctx->lo16));
   return 0;
 }
 
@@ -112,7 +112,7 @@ static Mlp3Group mk_mlp3(const float* x, const Lin32* L, float* y, int sigmoid_o
 }
 static bool mlp3_ok(const Lin32* L) { return L[0].K == 256 && L[0].N == 256 && L[1].K == 256 && L[1].N == 256 && L[2].K == 256; }
 static int tok_ln(sam2mi_ctx* ctx, hipStream_t s, float* x, const Norm& n, int T) {
-  CHK(layernorm_launch(x, 256, n.w, n.b, 1e-5f, T, 256, nullptr, 0, x, 256, 0, s));
+  CHK(layernorm_launch(x, 256, n.w, n.b, 1e-5f, T, 256, nullptr, 0, x, 256, 0, s, ctx->lo16));
   return 0;
 }
 
@@ -121,7 +121,7 @@ static int t2i_attention(sam2mi_ctx* ctx, hipStream_t s, const Lin32& Wq, const 
   float* q = ctx->d_tok;            // [N*T,256]
   const int R = N * T;
   // qq = q_proj(q + qpe)
-  CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, R, 256, nullptr, 0, ctx->d_tokpe, 256, s));
+  CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, R, 256, nullptr, 0, ctx->d_tokpe, 256, s, ctx->lo16));
   CHKI(tok_linear(ctx, s, ctx->d_tokpe, 256, Wq, ctx->d_t1, 128, R, 0));
   GemmParams pk = lin_params(ctx->d_kpe16, 256, N * 4096, Wk);
   pk.out32 = ctx->d_big1; pk.ld32 = 128;
@@ -138,8 +138,8 @@ static int t2i_attention(sam2mi_ctx* ctx, hipStream_t s, const Lin32& Wq, const 
 
 // refresh the f16 image-side operands from ctx->d_keys [N*4096,256]: keys16 = f16(keys), kpe16 = f16(keys + pos)
 static int refresh_key_operands(sam2mi_ctx* ctx, hipStream_t s, const float* pos_tok, bool pos_shared, int N) {
-  CHK(cast_add_launch(ctx->d_keys, 256, nullptr, 0, 0, 0.f, N * 4096, 256, ctx->d_keys16, 256, nullptr, 0, s));
-  CHK(cast_add_launch(ctx->d_keys, 256, pos_tok, 256, pos_shared ? 4096 : 0, 1.f, N * 4096, 256, ctx->d_kpe16, 256, nullptr, 0, s));
+  CHK(cast_add_launch(ctx->d_keys, 256, nullptr, 0, 0, 0.f, N * 4096, 256, ctx->d_keys16, 256, nullptr, 0, s, ctx->lo16));
+  CHK(cast_add_launch(ctx->d_keys, 256, pos_tok, 256, pos_shared ? 4096 : 0, 1.f, N * 4096, 256, ctx->d_kpe16, 256, nullptr, 0, s, ctx->lo16));
   return 0;
 }
 
@@ -157,7 +157,7 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
   // src = image_embeddings + dense_prompt_embeddings (mask_decoder.py:216)
   for (int n = 0; n < N; ++n)
     CHK(cast_add_launch(in.keys_tok + (size_t)n * in.keys_stride, 256, in.dense_tok ? in.dense_tok + (size_t)n * in.dense_stride : nullptr, 256,
-                        in.dense_rows >= 4096 ? 0 : 1, in.dense_tok ? 1.f : 0.f, 4096, 256, nullptr, 0, ctx->d_keys + (size_t)n * 4096 * 256, 256, s));
+                        in.dense_rows >= 4096 ? 0 : 1, in.dense_tok ? 1.f : 0.f, 4096, 256, nullptr, 0, ctx->d_keys + (size_t)n * 4096 * 256, 256, s, ctx->lo16));
   CHK(hipMemcpyAsync(ctx->d_tokens_in, in.tokens, (size_t)R * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));   // query_pe
   CHK(hipMemcpyAsync(ctx->d_tok, in.tokens, (size_t)R * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
   float* q = ctx->d_tok;
@@ -166,7 +166,7 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
     // ---- token self attention (layer 0: no pe, output replaces the queries; transformer.py:186-193)
     const float* qin = q;
     if (l > 0) {
-      CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, R, 256, nullptr, 0, ctx->d_tokpe, 256, s));
+      CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, R, 256, nullptr, 0, ctx->d_tokpe, 256, s, ctx->lo16));
       qin = ctx->d_tokpe;
     }
     {
@@ -194,7 +194,7 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
       GemmParams p = lin_params(ctx->d_kpe16, 256, M, L.i2t_q);
       p.out32 = ctx->d_big1; p.ld32 = 128;
       CHKI(run_gemm(ctx, s, p));
-      CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, R, 256, nullptr, 0, ctx->d_tokpe, 256, s));
+      CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, R, 256, nullptr, 0, ctx->d_tokpe, 256, s, ctx->lo16));
       {
         SmallLinBatch B;
         B.n = 2;
@@ -204,11 +204,11 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
       }
       CHK(small_attn_launch(ctx->d_big1, 128, ctx->d_t1, 128, ctx->d_t2, 128, ctx->d_big2, 128, 4096, T, 8, 16, N, (size_t)4096 * 128,
                             (size_t)T * 128, (size_t)4096 * 128, s));
-      CHK(cast_add_launch(ctx->d_big2, 128, nullptr, 0, 0, 0.f, M, 128, ctx->d_big16, 128, nullptr, 0, s));
+      CHK(cast_add_launch(ctx->d_big2, 128, nullptr, 0, 0, 0.f, M, 128, ctx->d_big16, 128, nullptr, 0, s, ctx->lo16));
       GemmParams o = lin_params(ctx->d_big16, 128, M, L.i2t_o);
       o.res = ctx->d_keys; o.ldres = 256; o.out32 = ctx->d_keys; o.ld32 = 256;
       CHKI(run_gemm(ctx, s, o));
-      CHK(layernorm_launch(ctx->d_keys, 256, L.n4.w, L.n4.b, 1e-5f, M, 256, nullptr, 0, ctx->d_keys, 256, 0, s));
+      CHK(layernorm_launch(ctx->d_keys, 256, L.n4.w, L.n4.b, 1e-5f, M, 256, nullptr, 0, ctx->d_keys, 256, 0, s, ctx->lo16));
     }
   }
   // ---- final token -> image attention + LN (transformer.py:134-139)
@@ -223,11 +223,11 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
     GemmParams p = lin_params(ctx->d_keys16, 256, M, ctx->dc1);
     p.out32 = ctx->d_g; p.ld32 = 256;
     CHKI(run_gemm(ctx, s, p));
-    CHK(upscale_glue_launch(ctx->d_g, 64, 64, ctx->dc1_b, in.hr1_tok, ctx->up_ln.w, ctx->up_ln.b, ctx->d_up1_16, N, in.hr1_stride, s));
+    CHK(upscale_glue_launch(ctx->d_g, 64, 64, ctx->dc1_b, in.hr1_tok, ctx->up_ln.w, ctx->up_ln.b, ctx->d_up1_16, N, in.hr1_stride, s, ctx->lo16));
     GemmParams p2 = lin_params(ctx->d_up1_16, 64, N * 16384, ctx->dc2);
     p2.out32 = ctx->d_g; p2.ld32 = 128;
     CHKI(run_gemm(ctx, s, p2));
-    CHK(upscale_glue_launch(ctx->d_g, 128, 32, ctx->dc2_b, in.hr0_tok, nullptr, nullptr, ctx->d_up2_16, N, in.hr0_stride, s));
+    CHK(upscale_glue_launch(ctx->d_g, 128, 32, ctx->dc2_b, in.hr0_tok, nullptr, nullptr, ctx->d_up2_16, N, in.hr0_stride, s, ctx->lo16));
   }
   // ---- hyper-network MLPs on the 4 mask tokens -> [N,4,32], IoU head (sigmoid) and object-score head: one launch
   {
@@ -241,7 +241,7 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
     B.g[5] = mk_mlp3(q, ctx->obj_head, ctx->d_obj, 0, (long)T * 256, 1);
     CHK(mlp3_launch(B, s));
   }
-  CHK(cast_add_launch(ctx->d_hyper, 32, nullptr, 0, 0, 0.f, N * 4, 32, ctx->d_hyper16, 32, nullptr, 0, s));
+  CHK(cast_add_launch(ctx->d_hyper, 32, nullptr, 0, 0, 0.f, N * 4, 32, ctx->d_hyper16, 32, nullptr, 0, s, ctx->lo16));
   // masks[n, i, pix] = sum_c hyper[n, i, c] * up[n, pix, c]   (GEMM over pixels, stored transposed)
   for (int n = 0; n < N; ++n) {
     GemmParams p = gemm_params_zero();
@@ -257,30 +257,30 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
 // vision features, mask1024 [1024*1024] already sigmoid-scaled -> out_tok64 [4096,64] f32.
 int memenc_forward(sam2mi_ctx* ctx, hipStream_t s, const float* feat2_tok, const float* mask1024, float* out_tok64) {
   // MaskDownSampler: 4 x (conv3x3 s2 + LN2d + GELU), then 1x1
-  CHK(conv3x3s2_ln_gelu_launch(mask1024, 1024, 1, 4, ctx->md_w[0], ctx->md_b[0], ctx->md_ln[0].w, ctx->md_ln[0].b, ctx->m_c1, nullptr, s));
-  CHK(conv3x3s2_ln_gelu_launch(ctx->m_c1, 512, 4, 16, ctx->md_w[1], ctx->md_b[1], ctx->md_ln[1].w, ctx->md_ln[1].b, nullptr, ctx->m_c2_16, s));
+  CHK(conv3x3s2_ln_gelu_launch(mask1024, 1024, 1, 4, ctx->md_w[0], ctx->md_b[0], ctx->md_ln[0].w, ctx->md_ln[0].b, ctx->m_c1, nullptr, s, ctx->lo16));
+  CHK(conv3x3s2_ln_gelu_launch(ctx->m_c1, 512, 4, 16, ctx->md_w[1], ctx->md_b[1], ctx->md_ln[1].w, ctx->md_ln[1].b, nullptr, ctx->m_c2_16, s, ctx->lo16));
   // conv 16 -> 64 as im2col + MFMA GEMM (K = 144), then LayerNorm2d + GELU
-  CHK(im2col3x3s2_launch(ctx->m_c2_16, 256, 16, ctx->m_col16, s));
+  CHK(im2col3x3s2_launch(ctx->m_c2_16, 256, 16, ctx->m_col16, s, ctx->lo16));
   {
     GemmParams p = lin_params(ctx->m_col16, 144, 16384, ctx->md_conv3);
     p.out32 = ctx->m_c4; p.ld32 = 64;
     CHKI(run_gemm(ctx, s, p));
   }
-  CHK(layernorm_launch(ctx->m_c4, 64, ctx->md_ln[2].w, ctx->md_ln[2].b, 1e-6f, 16384, 64, ctx->m_c3_16, 64, nullptr, 0, 1, s));
-  CHK(im2col3x3s2_launch(ctx->m_c3_16, 128, 64, ctx->m_col16, s));
+  CHK(layernorm_launch(ctx->m_c4, 64, ctx->md_ln[2].w, ctx->md_ln[2].b, 1e-6f, 16384, 64, ctx->m_c3_16, 64, nullptr, 0, 1, s, ctx->lo16));
+  CHK(im2col3x3s2_launch(ctx->m_c3_16, 128, 64, ctx->m_col16, s, ctx->lo16));
   {
     GemmParams p = lin_params(ctx->m_col16, 576, 4096, ctx->md_conv4);
     p.out32 = ctx->m_c4; p.ld32 = 256;
     CHKI(run_gemm(ctx, s, p));
   }
-  CHK(layernorm_launch(ctx->m_c4, 256, ctx->md_ln[3].w, ctx->md_ln[3].b, 1e-6f, 4096, 256, ctx->m_c4_16, 256, nullptr, 0, 1, s));
+  CHK(layernorm_launch(ctx->m_c4, 256, ctx->md_ln[3].w, ctx->md_ln[3].b, 1e-6f, 4096, 256, ctx->m_c4_16, 256, nullptr, 0, 1, s, ctx->lo16));
   {
     GemmParams p = lin_params(ctx->m_c4_16, 256, 4096, ctx->md_proj);
     p.out32 = ctx->m_emb; p.ld32 = 256;
     CHKI(run_gemm(ctx, s, p));
   }
   // x = pix_feat_proj(pix_feat) + mask embedding
-  CHK(cast_add_launch(feat2_tok, 256, nullptr, 0, 0, 0.f, 4096, 256, ctx->m_pix16, 256, nullptr, 0, s));
+  CHK(cast_add_launch(feat2_tok, 256, nullptr, 0, 0, 0.f, 4096, 256, ctx->m_pix16, 256, nullptr, 0, s, ctx->lo16));
   {
     GemmParams p = lin_params(ctx->m_pix16, 256, 4096, ctx->pix_proj);
     p.res = ctx->m_emb; p.ldres = 256; p.out32 = ctx->m_x; p.ld32 = 256;
@@ -289,7 +289,7 @@ int memenc_forward(sam2mi_ctx* ctx, hipStream_t s, const float* feat2_tok, const
   // Fuser: 2 x CXBlock (dwconv7 -> LN2d -> 256->1024 GELU -> 1024->256 -> gamma -> + x)
   for (int l = 0; l < 2; ++l) {
     CHK(dwconv7_launch(ctx->m_x, 64, 256, ctx->cx[l].dw_w, ctx->cx[l].dw_b, ctx->m_dw, s));
-    CHK(layernorm_launch(ctx->m_dw, 256, ctx->cx[l].ln.w, ctx->cx[l].ln.b, 1e-6f, 4096, 256, ctx->m_ln16, 256, nullptr, 0, 0, s));
+    CHK(layernorm_launch(ctx->m_dw, 256, ctx->cx[l].ln.w, ctx->cx[l].ln.b, 1e-6f, 4096, 256, ctx->m_ln16, 256, nullptr, 0, 0, s, ctx->lo16));
     GemmParams p = lin_params(ctx->m_ln16, 256, 4096, ctx->cx[l].pw1);
     p.act = ACT_GELU; p.out16 = ctx->m_h16; p.ld16 = 1024;
     CHKI(run_gemm(ctx, s, p));
@@ -297,7 +297,7 @@ int memenc_forward(sam2mi_ctx* ctx, hipStream_t s, const float* feat2_tok, const
     q.col_scale = ctx->cx[l].gamma; q.res = ctx->m_x; q.ldres = 256; q.out32 = ctx->m_x; q.ld32 = 256;
     CHKI(run_gemm(ctx, s, q));
   }
-  CHK(cast_add_launch(ctx->m_x, 256, nullptr, 0, 0, 0.f, 4096, 256, ctx->m_ln16, 256, nullptr, 0, s));
+  CHK(cast_add_launch(ctx->m_x, 256, nullptr, 0, 0, 0.f, 4096, 256, ctx->m_ln16, 256, nullptr, 0, s, ctx->lo16));
   {
     GemmParams p = lin_params(ctx->m_ln16, 256, 4096, ctx->me_out);
     p.out32 = out_tok64; p.ld32 = 64;

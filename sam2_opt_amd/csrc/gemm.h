@@ -28,6 +28,9 @@ struct GemmParams {
   const half_t* xs_pack;         // W in the piece order of the X-stationary kernel (gemm_xs.hip), or null
   const half_t* ks_pack;         // W in the piece order of the accumulator-stationary kernel (gemm_ks.hip: N = 576), or null
   int xs_scale_cols;             // col_scale is 1 from this column on (lets the X-stationary kernel keep only the q scale); 0: unknown
+  // split-f16 operands (f16x3 precision mode, common.h): lo arrays at these element offsets behind A / W (both or neither);
+  // out_lo_off != 0: out16 / outT16 are written as hi + lo
+  size_t a_lo_off, w_lo_off, out_lo_off;
 };
 
 static inline GemmParams gemm_params_zero() {

@@ -1,3 +1,5 @@
+// Dispatcher of the MFMA GEMMs (production kernel: gemm2.hip) + the first-session kernel, kept for A/B runs
+// (-DSAM2MI_EXPERIMENTAL, SAM2MI_GEMM_V1=1):
 // MFMA f16 GEMM for gfx950.  256 threads = 4 waves in a 2x2 grid, each wave owns a
 // (BM/2)x(BN/2) sub-tile built from 32x32x16 MFMAs.  Global->register->LDS staging with
 // the loads of tile k+1 issued before the MFMAs of tile k (one barrier per K-tile); LDS rows
@@ -7,6 +9,7 @@
 
 #include "gemm.h"
 
+#ifdef SAM2MI_EXPERIMENTAL
 template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmParams p) {
   constexpr int BKP = BK + 8;
@@ -193,19 +196,24 @@ static hipError_t gemm_attr() {
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_smem<BM, BN, BK>());
 }
 
+#endif  // SAM2MI_EXPERIMENTAL
+
 hipError_t gemm_init() {
+#ifdef SAM2MI_EXPERIMENTAL
   hipError_t e[9] = {
       gemm_attr<128, 128, 64>(), gemm_attr<128, 128, 48>(), gemm_attr<128, 128, 32>(),
       gemm_attr<128, 64, 64>(),  gemm_attr<128, 64, 48>(),  gemm_attr<128, 64, 32>(),
       gemm_attr<64, 64, 64>(),   gemm_attr<64, 64, 48>(),   gemm_attr<64, 64, 32>()};
   for (int i = 0; i < 9; ++i)
     if (e[i] != hipSuccess) return e[i];
-  hipError_t e2 = gemm_v2_init();
-  if (e2 != hipSuccess) return e2;
   hipError_t e3 = gemm_v3_init();
-  return e3 != hipSuccess ? e3 : gemm_p4_init();
+  if (e3 == hipSuccess) e3 = gemm_p4_init();
+  if (e3 != hipSuccess) return e3;
+#endif
+  return gemm_v2_init();
 }
 
+#ifdef SAM2MI_EXPERIMENTAL
 template <int BK>
 static hipError_t gemm_dispatch_tile(const GemmParams& p, hipStream_t s) {
   const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
@@ -214,14 +222,22 @@ static hipError_t gemm_dispatch_tile(const GemmParams& p, hipStream_t s) {
   if (t12864 >= 256) return gemm_launch_t<128, 64, BK>(p, s);
   return gemm_launch_t<64, 64, BK>(p, s);
 }
+#endif
 
+// Every linear of the model has K % 16 == 0 and runs on the LDS-DMA kernel (gemm2.hip).
 hipError_t gemm_launch(const GemmParams& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if ((p.lda & 7) || (p.ldw & 7) || (p.n_split < p.N && (p.n_split & 31)) || p.K <= 0) return hipErrorInvalidValue;
-  static const bool use_v1 = getenv("SAM2MI_GEMM_V1") != nullptr;      // A/B switch: the register-staged kernel below
-  if (!use_v1 && (p.K & 15) == 0) return gemm_v2_launch(p, s);
-  if (p.K % 64 == 0) return gemm_dispatch_tile<64>(p, s);
-  if (p.K % 48 == 0) return gemm_dispatch_tile<48>(p, s);
-  if (p.K % 32 == 0) return gemm_dispatch_tile<32>(p, s);
-  return hipErrorInvalidValue;
+#ifdef SAM2MI_EXPERIMENTAL
+  static const bool use_v1 = getenv("SAM2MI_GEMM_V1") != nullptr;      // A/B switch: the register-staged first-session kernel
+  if (use_v1 || (p.K & 15)) {
+    if (p.a_lo_off) return hipErrorInvalidValue;
+    if (p.K % 64 == 0) return gemm_dispatch_tile<64>(p, s);
+    if (p.K % 48 == 0) return gemm_dispatch_tile<48>(p, s);
+    if (p.K % 32 == 0) return gemm_dispatch_tile<32>(p, s);
+    return hipErrorInvalidValue;
+  }
+#endif
+  if (p.K & 15) return hipErrorInvalidValue;
+  return gemm_v2_launch(p, s);
 }

@@ -27,18 +27,23 @@ namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-template <int BM, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8) ? 1 : 2) void gemm_v2_kernel(const GemmParams p) {
+// SPLIT (the "f16x3" precision mode): both operands arrive as two f16 arrays, hi = f16(v) and lo = f16((v - hi) * 2^11) at
+// p.a_lo_off / p.w_lo_off elements behind the hi array.  A stage holds [A_hi | B_hi | A_lo | B_lo]; every fragment pair
+// costs three MFMAs: hi*hi into the main accumulator, lo*hi + hi*lo into a second one that is folded in (x 2^-11) before the
+// epilogue.  The dropped lo*lo term is 2^-22 relative; the 2^11 scale keeps the lo parts in the normal f16 range.
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT = false>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8 || SPLIT) ? 1 : 2) void gemm_v2_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, HALF_STAGE = A_BYTES + B_BYTES, STAGE = HALF_STAGE * (SPLIT ? 2 : 1);
   constexpr int A_CALLS = BM / 8 / NW, B_CALLS = BN / 8 / NW;     // 1-KiB pieces per wave
   // EVEN: A and B pieces split evenly over the waves.  Otherwise (12-wave 256x192 workgroup) the PA + PB pieces of a K
   // tile are dealt round-robin, piece q = wave + j * NW (A pieces first); STAGES == 2 only (vmcnt is always drained to 0).
   constexpr bool EVEN = (BM / 8) % NW == 0 && (BN / 8) % NW == 0;
   constexpr int PA = BM / 8, PB = BN / 8, NJ = (PA + PB + NW - 1) / NW;
   static_assert(EVEN || STAGES == 2, "uneven piece split needs the 2-stage ring");
+  static_assert(EVEN || !SPLIT, "split operands need the even piece split");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -50,12 +55,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8) ? 1 : 2) void gemm_v2_k
   const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
 
   f32x16 acc[TM][TN];
+  f32x16 accx[SPLIT ? TM : 1][SPLIT ? TN : 1];       // cross terms (scaled by 2^11)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if constexpr (SPLIT) accx[i][j][r] = 0.f;
+      }
 
   const int nk = (p.K + 63) / 64;
   const int srow = lane >> 3, spc = lane & 7;        // row-in-piece and physical 16-B slot of this lane
@@ -107,6 +116,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8) ? 1 : 2) void gemm_v2_k
 #pragma unroll
       for (int j = 0; j < B_CALLS; ++j)
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + b_off[j]), (lds_ptr_t)(sbase + A_BYTES + (wave * B_CALLS + j) * 1024), 16, 0, 0);
+      if constexpr (SPLIT) {
+        const char* kal = ka + p.a_lo_off * 2;
+        const char* kbl = kb + p.w_lo_off * 2;
+#pragma unroll
+        for (int j = 0; j < A_CALLS; ++j)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kal + a_off[j]), (lds_ptr_t)(sbase + HALF_STAGE + (wave * A_CALLS + j) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < B_CALLS; ++j)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbl + b_off[j]), (lds_ptr_t)(sbase + HALF_STAGE + A_BYTES + (wave * B_CALLS + j) * 1024), 16, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -118,19 +137,23 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8) ? 1 : 2) void gemm_v2_k
   };
 
   // ---- K pipeline: STAGES-1 tiles in flight, counted vmcnt + raw barrier (a __syncthreads() would drain the DMA queue)
-  constexpr int NPW = A_CALLS + B_CALLS;           // LDS-DMA pieces this wave issues per K tile
-  struct Frag { half8 a[TM]; half8 b[TN]; };
+  constexpr int NPW = (A_CALLS + B_CALLS) * (SPLIT ? 2 : 1);           // LDS-DMA pieces this wave issues per K tile
+  struct Frag { half8 a[TM]; half8 b[TN]; half8 al[SPLIT ? TM : 1]; half8 bl[SPLIT ? TN : 1]; };
   auto ldfrag = [&](const char* sA, const char* sB, int s) {
     Frag f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row = wm * WTM + i * 32 + fr;
-      f.a[i] = *reinterpret_cast<const half8*>(sA + row * 128 + (((2 * s + fh) ^ ((row >> 1) & 7)) << 4));
+      const int off = row * 128 + (((2 * s + fh) ^ ((row >> 1) & 7)) << 4);
+      f.a[i] = *reinterpret_cast<const half8*>(sA + off);
+      if constexpr (SPLIT) f.al[i] = *reinterpret_cast<const half8*>(sA + HALF_STAGE + off);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int row = wn * WTN + j * 32 + fr;
-      f.b[j] = *reinterpret_cast<const half8*>(sB + row * 128 + (((2 * s + fh) ^ ((row >> 1) & 7)) << 4));
+      const int off = row * 128 + (((2 * s + fh) ^ ((row >> 1) & 7)) << 4);
+      f.b[j] = *reinterpret_cast<const half8*>(sB + off);
+      if constexpr (SPLIT) f.bl[j] = *reinterpret_cast<const half8*>(sB + HALF_STAGE + off);
     }
     return f;
   };
@@ -138,7 +161,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8) ? 1 : 2) void gemm_v2_k
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(f.a[i], f.b[j], acc[i][j]);
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = mfma32(f.a[i], f.b[j], acc[i][j]);
+        if constexpr (SPLIT) {
+          accx[i][j] = mfma32(f.al[i], f.b[j], accx[i][j]);
+          accx[i][j] = mfma32(f.a[i], f.bl[j], accx[i][j]);
+        }
+      }
   };
   auto sync_tile = [&](int kt) {                   // tile kt landed & visible; slot of tile kt-1 free; keep the ring full
     const int later = min(STAGES - 2, nk - 1 - kt);
@@ -179,6 +208,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8) ? 1 : 2) void gemm_v2_k
       const Frag f = ldfrag(sA, sB, s);
       mma(f);
     }
+  }
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = fmaf(accx[i][j][r], SPLIT_INV, acc[i][j][r]);
   }
   __syncthreads();              // every wave is done with the ring before the epilogue patches overwrite it
 
@@ -232,8 +269,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8) ? 1 : 2) void gemm_v2_k
             }
             if (mg + 3 < p.M) {
               if (p.outT16) {
-                const half4 h = {(half_t)w4[0], (half_t)w4[1], (half_t)w4[2], (half_t)w4[3]};
-                *reinterpret_cast<half4*>(p.outT16 + (size_t)nt * p.ldT16 + mg) = h;
+                const f32x4 f = {w4[0], w4[1], w4[2], w4[3]};
+                store_h4(p.outT16 + (size_t)nt * p.ldT16 + mg, p.out_lo_off, f);
               }
               if (p.outT32) {
                 const f32x4 f = {w4[0], w4[1], w4[2], w4[3]};
@@ -243,7 +280,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8) ? 1 : 2) void gemm_v2_k
 #pragma unroll
               for (int r = 0; r < 4; ++r)
                 if (mg + r < p.M) {
-                  if (p.outT16) p.outT16[(size_t)nt * p.ldT16 + mg + r] = (half_t)w4[r];
+                  if (p.outT16) store_h1(p.outT16 + (size_t)nt * p.ldT16 + mg + r, p.out_lo_off, w4[r]);
                   if (p.outT32) p.outT32[(size_t)nt * p.ldT32 + mg + r] = w4[r];
                 }
             }
@@ -275,8 +312,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8) ? 1 : 2) void gemm_v2_k
               *reinterpret_cast<f32x4*>(p.out32 + (size_t)m * p.ld32 + nn) = ov;
             }
             if (p.out16) {
-              const half4 hv = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-              *reinterpret_cast<half4*>(p.out16 + (size_t)m * p.ld16 + nn) = hv;
+              const f32x4 ov = {o[0], o[1], o[2], o[3]};
+              store_h4(p.out16 + (size_t)m * p.ld16 + nn, p.out_lo_off, ov);
             }
           } else {
 #pragma unroll
@@ -285,7 +322,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8) ? 1 : 2) void gemm_v2_k
                 float x = o[e];
                 if (p.res) x += p.res[rrow * p.ldres + nn + e];
                 if (p.out32) p.out32[(size_t)m * p.ld32 + nn + e] = x;
-                if (p.out16) p.out16[(size_t)m * p.ld16 + nn + e] = (half_t)x;
+                if (p.out16) store_h1(p.out16 + (size_t)m * p.ld16 + nn + e, p.out_lo_off, x);
               }
             }
           }
@@ -297,29 +334,35 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8) ? 1 : 2) void gemm_v2_k
   }
 }
 
-template <int BM, int BN, int STAGES>
-constexpr size_t v2_smem() { return (size_t)STAGES * (BM + BN) * 128; }
+template <int BM, int BN, int STAGES, bool SPLIT = false>
+constexpr size_t v2_smem() { return (size_t)STAGES * (BM + BN) * 128 * (SPLIT ? 2 : 1); }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT = false>
 hipError_t v2_launch(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  const size_t smem = v2_smem<BM, BN, STAGES>();
-  gemm_v2_kernel<BM, BN, WM, WN, STAGES><<<dim3(tiles), dim3(WM * WN * 64), smem, s>>>(p);
+  const size_t smem = v2_smem<BM, BN, STAGES, SPLIT>();
+  gemm_v2_kernel<BM, BN, WM, WN, STAGES, SPLIT><<<dim3(tiles), dim3(WM * WN * 64), smem, s>>>(p);
   return hipGetLastError();
 }
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT = false>
 hipError_t v2_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v2_kernel<BM, BN, WM, WN, STAGES>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_smem<BM, BN, STAGES>());
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v2_kernel<BM, BN, WM, WN, STAGES, SPLIT>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_smem<BM, BN, STAGES, SPLIT>());
 }
 }  // namespace
 
 hipError_t gemm_v2_init() {
-  hipError_t e[15] = {v2_attr<128, 192, 4, 2, 2>(), v2_attr<256, 192, 4, 2, 2>(), v2_attr<256, 256, 4, 4, 2>(), v2_attr<256, 192, 4, 3, 2>(), v2_attr<256, 128, 4, 2, 3>(), v2_attr<128, 128, 2, 2, 2>(), v2_attr<128, 64, 2, 2, 2>(), v2_attr<64, 64, 2, 2, 2>(),
-                      v2_attr<128, 64, 2, 2, 3>(), v2_attr<128, 128, 2, 2, 3>(), v2_attr<64, 64, 2, 2, 4>(),
-                      v2_attr<128, 128, 4, 2, 2>(), v2_attr<256, 128, 4, 2, 2>(), v2_attr<256, 64, 4, 2, 2>(), v2_attr<128, 64, 4, 2, 2>()};
-  for (int i = 0; i < 15; ++i)
-    if (e[i] != hipSuccess) return e[i];
+  const hipError_t e[] = {
+      v2_attr<128, 192, 4, 2, 2>(), v2_attr<128, 128, 4, 2, 2>(), v2_attr<128, 64, 4, 2, 2>(), v2_attr<64, 64, 2, 2, 2>(),
+      v2_attr<128, 128, 4, 2, 2, true>(), v2_attr<128, 64, 4, 2, 2, true>(), v2_attr<64, 64, 2, 2, 2, true>(),
+#ifdef SAM2MI_EXPERIMENTAL
+      v2_attr<256, 192, 4, 2, 2>(), v2_attr<256, 256, 4, 4, 2>(), v2_attr<256, 192, 4, 3, 2>(), v2_attr<256, 128, 4, 2, 3>(), v2_attr<128, 128, 2, 2, 2>(),
+      v2_attr<128, 64, 2, 2, 2>(), v2_attr<128, 64, 2, 2, 3>(), v2_attr<128, 128, 2, 2, 3>(), v2_attr<64, 64, 2, 2, 4>(), v2_attr<256, 128, 4, 2, 2>(),
+      v2_attr<256, 64, 4, 2, 2>(),
+#endif
+  };
+  for (hipError_t x : e)
+    if (x != hipSuccess) return x;
   return hipSuccess;
 }
 
@@ -331,29 +374,43 @@ static inline long tiles_of(const GemmParams& p, int bm, int bn) { return (long)
 // 8-wave workgroups beat 4-wave ones on every large shape; 128x128 (2 per CU) wins when N pads to 128 with <= 8 % waste,
 // 128x64 (3 per CU) otherwise; 256x128 and 3/4-stage rings (1 workgroup per CU) lose 30-50 %, 16-wave 256x128 3-stage
 // workgroups lose 10 %, a 256x256 8-wave tile on this loop structure loses 50 % (it needs the fine-grained multi-phase
-// schedule, not more bytes per barrier; re-measured after making sure its accumulators stay in registers - with the tile
-// loops of the epilogue merely "#pragma unroll"ed the 8-tile body is not unrolled, acc[][] is indexed dynamically and lands
-// in scratch).  The loop is bound by the per-CU L2->LDS rate (~25-29 B/clk) at these tiles.
+// schedule, not more bytes per barrier).  The loop is bound by the per-CU L2->LDS rate (~25-29 B/clk) at these tiles.
+// The losing tiles are only compiled with -DSAM2MI_EXPERIMENTAL (tile_hint, tools/gemm_bench.py).
 hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
+  if (p.a_lo_off || p.w_lo_off) {                        // split-f16 operands (f16x3 precision mode)
+    if (!p.a_lo_off || !p.w_lo_off) return hipErrorInvalidValue;
+    switch (gemm_v2_auto_tile(p)) {
+      case 3:
+      case 2: return v2_launch<128, 128, 4, 2, 2, true>(p, s);
+      case 1: return v2_launch<128, 64, 4, 2, 2, true>(p, s);
+      default: return v2_launch<64, 64, 2, 2, 2, true>(p, s);
+    }
+  }
+#ifdef SAM2MI_EXPERIMENTAL
   const int force = p.tile_hint;
   if (force == 6) return gemm_v3_launch(p, s);
-  if (force == 20 && (p.K & 63) == 0) return gemm_p4_launch(p, s);          // experimental 256x256 staggered kernel (else: automatic)
+  if (force == 20 && (p.K & 63) == 0) return gemm_p4_launch(p, s);          // 256x256 staggered kernel (else: automatic)
   if (force == 2) return v2_launch<256, 128, 4, 2, 3>(p, s);
   if (force == 3) return v2_launch<128, 128, 2, 2, 2>(p, s);
   if (force == 7) return v2_launch<128, 64, 2, 2, 3>(p, s);
   if (force == 8) return v2_launch<128, 128, 2, 2, 3>(p, s);
   if (force == 9) return v2_launch<64, 64, 2, 2, 4>(p, s);
-  if (force == 10) return v2_launch<128, 128, 4, 2, 2>(p, s);
   if (force == 11) return v2_launch<256, 128, 4, 2, 2>(p, s);
   if (force == 12) return v2_launch<256, 64, 4, 2, 2>(p, s);
-  if (force == 13) return v2_launch<128, 64, 4, 2, 2>(p, s);
-  if (force == 16) return v2_launch<128, 192, 4, 2, 2>(p, s);
   if (force == 17) return v2_launch<256, 192, 4, 2, 2>(p, s);
   if (force == 14) return v2_launch<256, 256, 4, 4, 2>(p, s);
   if (force == 15) return v2_launch<256, 192, 4, 3, 2>(p, s);
   if (force == 4) return v2_launch<128, 64, 2, 2, 2>(p, s);
-  if (force == 5) return v2_launch<64, 64, 2, 2, 2>(p, s);
-  switch (gemm_v2_auto_tile(p)) {
+#endif
+  int tile = gemm_v2_auto_tile(p);
+  switch (p.tile_hint) {                                 // the four production tiles can be forced (benchmarks, parity tests)
+    case 16: tile = 3; break;
+    case 10: tile = 2; break;
+    case 13: tile = 1; break;
+    case 5: tile = 0; break;
+    default: break;
+  }
+  switch (tile) {
     case 3: return v2_launch<128, 192, 4, 2, 2>(p, s);
     case 2: return v2_launch<128, 128, 4, 2, 2>(p, s);
     case 1: return v2_launch<128, 64, 4, 2, 2>(p, s);
@@ -365,8 +422,7 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
 int gemm_v2_auto_tile(const GemmParams& p) {
   // long K, N a multiple of 192 (fc2 of stages 3-4: N = 576 / 1152): the 128x192 tile re-reads the A panel N/192 instead of
   // N/64 times through the L2->LDS path that bounds this kernel (measured +14 % / +16 % on those two shapes)
-  static const bool no_t192 = getenv("SAM2MI_NO_T192") != nullptr;      // A/B aid
-  if (!no_t192 && p.N % 192 == 0 && p.K >= 2048 && p.M >= 4096) return 3;
+  if (p.N % 192 == 0 && p.K >= 2048 && p.M >= 4096) return 3;
   const int n128 = ((p.N + 127) / 128) * 128;
   const long t128 = tiles_of(p, 128, 128);
   const bool fits128 = (n128 - p.N) * 100 <= 8 * p.N;              // N pads to 128 with at most 8 % waste
@@ -378,7 +434,9 @@ int gemm_v2_auto_tile(const GemmParams& p) {
 // kernel name as rocprofv3 prints it (profiling by instantiation)
 const char* gemm_v2_kernel_name(const GemmParams& p) {
   if (p.tile_hint != 0) return "gemm_v2_kernel<forced tile>";
-  static const char* names[4] = {"gemm_v2_kernel<64, 64, 2, 2, 2>", "gemm_v2_kernel<128, 64, 4, 2, 2>", "gemm_v2_kernel<128, 128, 4, 2, 2>",
-                                 "gemm_v2_kernel<128, 192, 4, 2, 2>"};
-  return names[gemm_v2_auto_tile(p)];
+  static const char* names[4] = {"gemm_v2_kernel<64, 64, 2, 2, 2, false>", "gemm_v2_kernel<128, 64, 4, 2, 2, false>", "gemm_v2_kernel<128, 128, 4, 2, 2, false>",
+                                 "gemm_v2_kernel<128, 192, 4, 2, 2, false>"};
+  static const char* split_names[4] = {"gemm_v2_kernel<64, 64, 2, 2, 2, true>", "gemm_v2_kernel<128, 64, 4, 2, 2, true>", "gemm_v2_kernel<128, 128, 4, 2, 2, true>",
+                                       "gemm_v2_kernel<128, 128, 4, 2, 2, true>"};
+  return (p.a_lo_off ? split_names : names)[gemm_v2_auto_tile(p)];
 }

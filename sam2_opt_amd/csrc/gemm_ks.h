@@ -10,8 +10,16 @@ struct GemmKsParams {
   float* out32; int ld32;          // [M, 576] f32
   int M, K;                        // K % 64 == 0
 };
+#ifdef SAM2MI_EXPERIMENTAL      // parity-tested, equal end to end to the tiled kernel on stage-3 fc2: not in the default build
 bool gemm_ks_supported(int N, int K);                 // N == 576, K % 64 == 0
 size_t gemm_ks_pack_bytes(int N, int K);
 hipError_t gemm_ks_pack(const half_t* w, int N, int K, int ldw, half_t* wpack, hipStream_t s);
 hipError_t gemm_ks_launch(const GemmKsParams& p, hipStream_t s);
 hipError_t gemm_ks_init();
+#else
+static inline bool gemm_ks_supported(int, int) { return false; }
+static inline size_t gemm_ks_pack_bytes(int, int) { return 0; }
+static inline hipError_t gemm_ks_pack(const half_t*, int, int, int, half_t*, hipStream_t) { return hipErrorNotSupported; }
+static inline hipError_t gemm_ks_launch(const GemmKsParams&, hipStream_t) { return hipErrorNotSupported; }
+static inline hipError_t gemm_ks_init() { return hipSuccess; }
+#endif

@@ -130,7 +130,7 @@ __global__ void dense_pe_kernel(const float* __restrict__ gauss, int S, float* _
 __global__ __launch_bounds__(256) void upscale_glue_kernel(const float* __restrict__ g, int Hin, int C, const float* __restrict__ bias,
                                                            const float* __restrict__ hr, const float* __restrict__ lnw,
                                                            const float* __restrict__ lnb, half_t* __restrict__ out16,
-                                                           size_t hr_bstride) {
+                                                           size_t hr_bstride, size_t lo_off) {
   const int Hout = 2 * Hin;
   g += (size_t)blockIdx.y * Hin * Hin * 4 * C;           // batch: contiguous inputs / outputs, hr shared when its stride is 0
   hr += blockIdx.y * hr_bstride;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void upscale_glue_kernel(const float* __restri
     const float rstd = 1.f / sqrtf(wave_sum(d * d) / C + 1e-6f);
     v = on ? d * rstd * lnw[lane] + lnb[lane] : 0.f;
   }
-  if (on) out16[(size_t)pix * C + lane] = (half_t)gelu_erf(v);
+  if (on) store_h1(out16 + (size_t)pix * C + lane, lo_off, gelu_erf(v));
 }
 
 // stability score inputs of MaskDecoder._get_stability_scores (mask_decoder.py:332-344) for mask 0
@@ -229,8 +229,8 @@ __global__ void mem_assemble_kernel(const MemAssembleParams p) {
     f = p.ptr_tok[r];
     ps = p.ptr_pos[r];
   }
-  p.kin[i] = (half_t)(f + ps);
-  p.vin[i] = (half_t)f;
+  store_h1(p.kin + i, p.lo_off, f + ps);
+  store_h1(p.vin + i, p.lo_off, f);
   if (p.mem32) p.mem32[i] = f;
   if (p.mempos32) p.mempos32[i] = ps;
 }
@@ -289,10 +289,10 @@ hipError_t dense_pe_launch(const float* gauss, int S, float* out, hipStream_t s)
   return hipGetLastError();
 }
 hipError_t upscale_glue_launch(const float* g, int Hin, int C, const float* bias, const float* hr, const float* lnw,
-                               const float* lnb, half_t* out16, int batch, size_t hr_bstride, hipStream_t s) {
+                               const float* lnb, half_t* out16, int batch, size_t hr_bstride, hipStream_t s, size_t lo_off) {
   if (C > 64 || batch < 1 || batch > 65535) return hipErrorInvalidValue;
   const int n = 4 * Hin * Hin;
-  upscale_glue_kernel<<<dim3((n + 3) / 4, batch), dim3(256), 0, s>>>(g, Hin, C, bias, hr, lnw, lnb, out16, hr_bstride);
+  upscale_glue_kernel<<<dim3((n + 3) / 4, batch), dim3(256), 0, s>>>(g, Hin, C, bias, hr, lnw, lnb, out16, hr_bstride, lo_off);
   return hipGetLastError();
 }
 hipError_t select_mask_launch(const float* masks, const float* iou, const float* obj, const float* tokens, int multimask,

@@ -1,20 +1,22 @@
 // Launchers for the non-GEMM, non-attention kernels (elementwise.hip, convs.hip, heads.hip).
 // All take raw device pointers; token-major ("tok") tensors are [rows, channels] row-major.
+// `lo_off` (f16 producers): 0, or the element offset of the lo array of the split-f16 precision mode (common.h) - the
+// kernel then writes hi at the given pointer and lo at pointer + lo_off.
 #pragma once
 #include "common.h"
 
 // ---------------------------------------------------------------- elementwise.hip
 // LayerNorm over the last dim of x [M, C] (ldx) -> y16 (f16, ldy16) and/or y32 (f32, ldy32); act: 0 none, 1 GELU
 hipError_t layernorm_launch(const float* x, int ldx, const float* w, const float* b, float eps, int M, int C,
-                            half_t* y16, int ldy16, float* y32, int ldy32, int act, hipStream_t s);
+                            half_t* y16, int ldy16, float* y32, int ldy32, int act, hipStream_t s, size_t lo_off = 0);
 // y16[m, c] = f16(a[m, c] + sb * b[(m % bmod), c]);  b may be null; bmod == 0 -> m.  Optional y32 copy.
 hipError_t cast_add_launch(const float* a, int lda, const float* b, int ldb, int bmod, float sb, int M, int C,
-                           half_t* y16, int ldy16, float* y32, int ldy32, hipStream_t s);
+                           half_t* y16, int ldy16, float* y32, int ldy32, hipStream_t s, size_t lo_off = 0);
 // patch-embed im2col: img [B,3,S,S] f32 -> A [B*(S/4)^2, 160] f16, rows in window-major (w=8) token order,
 // column k = c*49 + ky*7 + kx (conv 7x7, stride 4, pad 3); columns 147..159 are zero.
-hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStream_t s);
+hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStream_t s, size_t lo_off = 0);
 // same from decoded frames: uint8 [B, S, S, 3] HWC, normalised ((v/255 - mean)/std, ImageNet constants) on the fly
-hipError_t im2col_patch_u8_launch(const uint8_t* img_hwc, int B, int S, half_t* A, hipStream_t s);
+hipError_t im2col_patch_u8_launch(const uint8_t* img_hwc, int B, int S, half_t* A, hipStream_t s, size_t lo_off = 0);
 // 2x2 max-pool inside w x w windows of window-major tokens: in [nwin*w*w, C] -> out [nwin*(w/2)^2, C]
 hipError_t pool_tokens_f32_launch(const float* in, int ldin, float* out, int ldout, int nwin, int w, int C, hipStream_t s);
 hipError_t pool_tokens_f16_launch(const half_t* in, int ldin, half_t* out, int ldout, int nwin, int w, int C, hipStream_t s);
@@ -36,9 +38,9 @@ hipError_t fill_f32_launch(float* p, float v, size_t n, hipStream_t s);
 hipError_t mask_prep_launch(const float* low, float* out, int binarize, float scale, float bias, hipStream_t s);
 // direct conv 3x3 stride 2 pad 1 on NHWC f32 + bias + LayerNorm2d(eps 1e-6) + GELU; in [Hin*Hin, CIN] -> out [Hout*Hout, COUT]
 hipError_t conv3x3s2_ln_gelu_launch(const float* in, int Hin, int CIN, int COUT, const float* w, const float* b,
-                                    const float* lnw, const float* lnb, float* out32, half_t* out16, hipStream_t s);
+                                    const float* lnw, const float* lnb, float* out32, half_t* out16, hipStream_t s, size_t lo_off = 0);
 // im2col for a 3x3 s2 p1 conv on NHWC f16: in [Hin*Hin, CIN] -> A [Hout*Hout, 9*CIN], column (ky*3+kx)*CIN + c
-hipError_t im2col3x3s2_launch(const half_t* in, int Hin, int CIN, half_t* A, hipStream_t s);
+hipError_t im2col3x3s2_launch(const half_t* in, int Hin, int CIN, half_t* A, hipStream_t s, size_t lo_off = 0);
 // depth-wise 7x7 pad 3 on NHWC f32 [H*H, C]; w [C, 49]
 hipError_t dwconv7_launch(const float* in, int H, int C, const float* w, const float* b, float* out, hipStream_t s);
 
@@ -83,7 +85,7 @@ hipError_t dense_pe_launch(const float* gauss, int S, float* out, hipStream_t s)
 // -> (LayerNorm2d if lnw) -> GELU -> out16 [(2Hin)^2, C]
 // `batch` images back to back in g / out16; hr advances by hr_bstride floats per image (0: shared)
 hipError_t upscale_glue_launch(const float* g, int Hin, int C, const float* bias, const float* hr, const float* lnw,
-                               const float* lnb, half_t* out16, int batch, size_t hr_bstride, hipStream_t s);
+                               const float* lnb, half_t* out16, int batch, size_t hr_bstride, hipStream_t s, size_t lo_off = 0);
 // SAM-head selection on device (SAM2Base._forward_sam_heads :440-484, MaskDecoder.forward :151-169):
 //  masks [4, 65536], iou [4], obj [1], tokens [4,256]  ->  low_sel [65536] (NO_OBJ filled when obj<=0),
 //  tok_sel [256], best_idx [1].  multimask: argmax-IoU over candidates 1..3; otherwise candidate 0 with the
@@ -100,6 +102,7 @@ struct MemAssembleParams {
   const float* pos;                                          // maskmem_pos_enc [4096,64]
   const float* ptr_tok; const float* ptr_pos; int P;         // [P,64] each (already split into 64-wide tokens)
   half_t* kin; half_t* vin;                                  // [L*4096 + P (padded), 64]
+  size_t lo_off;                                             // split-f16 mode: lo planes of kin / vin (0: off)
   float* mem32; float* mempos32;                             // optional f32 copies (plug-format debugging)
 };
 hipError_t mem_assemble_launch(const MemAssembleParams& p, hipStream_t s);

@@ -27,7 +27,11 @@ EXPORTS = [
 class Sam2miConfig(C.Structure):
     _fields_ = [("embed_dim", C.c_int), ("num_heads", C.c_int), ("stages", C.c_int * 4),
                 ("global_att_blocks", C.c_int * 8), ("window_spec", C.c_int * 4), ("image_size", C.c_int),
-                ("max_batch", C.c_int), ("bank_slots", C.c_int), ("feat_slots", C.c_int)]
+                ("max_batch", C.c_int), ("bank_slots", C.c_int), ("feat_slots", C.c_int), ("precision", C.c_int)]
+
+
+ABI_VERSION = 2
+PRECISIONS = {"f16": 0, "f16x3": 1}      # SAM2MI_PRECISION_* (include/sam2mi.h)
 
 
 class MemSelect(C.Structure):
@@ -60,6 +64,9 @@ def load_library() -> C.CDLL:
         for name in EXPORTS:
             if not hasattr(lib, name):
                 raise RuntimeError(f"libsam2mi.so does not export {name}")
+        if lib.sam2mi_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libsam2mi.so has ABI version {lib.sam2mi_abi_version()}, this binding needs {ABI_VERSION}: "
+                               "rebuild with `python -m sam2_opt_amd.build`")
         lib.sam2mi_last_error.restype = C.c_char_p
         lib.sam2mi_last_error.argtypes = [C.c_void_p]
         lib.sam2mi_create.argtypes = [C.POINTER(Sam2miConfig), C.POINTER(C.c_void_p)]
@@ -85,7 +92,12 @@ class Engine:
     """One sam2mi context (one per host thread / stream)."""
 
     def __init__(self, model: str = "large", state_dict=None, max_batch: int = 1, bank_slots: int = 64,
-                 feat_slots: int = 16, device: Optional[torch.device] = None):
+                 feat_slots: int = 16, device: Optional[torch.device] = None, precision: str = "f16"):
+        """`precision`: "f16" (default: f16 MFMA operands, f32 accumulation) or "f16x3" (every MFMA operand as a 2-term f16
+        split, three MFMAs per product: the "masks within 1e-3 of the reference" class at 2-3x the MFMA work)."""
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        self.precision = precision
         if not torch.cuda.is_available():
             raise RuntimeError("sam2_opt_amd needs a ROCm GPU (MI355X); no CPU fallback exists")
         self.lib = load_library()
@@ -103,6 +115,7 @@ class Engine:
         for i in range(8):
             c.global_att_blocks[i] = self.cfg["global_att_blocks"][i] if i < len(self.cfg["global_att_blocks"]) else -1
         c.max_batch, c.bank_slots, c.feat_slots = max_batch, bank_slots, max(feat_slots, max_batch)
+        c.precision = PRECISIONS[precision]
         self.max_batch, self.bank_slots, self.feat_slots = max_batch, bank_slots, c.feat_slots
         h = C.c_void_p()
         if self.lib.sam2mi_create(C.byref(c), C.byref(h)) != 0:

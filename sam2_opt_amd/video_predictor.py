@@ -31,7 +31,7 @@ from .synthetic import normalize_frames
 class SAM2VideoPredictor:
     def __init__(self, model: str = "large", state_dict=None, ckpt_path: Optional[str] = None, device=None,
                  encode_batch: int = 8, bank_slots: int = 384, fill_hole_area: int = 0, non_overlap_masks: bool = False,
-                 overlap_encode: bool = True):
+                 overlap_encode: bool = True, precision: str = "f16"):
         self.cfg = get_config(model)
         if state_dict is None and ckpt_path is not None:
             # same contract as build_sam._load_checkpoint (build_sam.py:164-174)
@@ -40,7 +40,7 @@ class SAM2VideoPredictor:
             raise ValueError("state_dict or ckpt_path is required")
         self.encode_batch = int(encode_batch)
         self.engine = Engine(self.cfg, state_dict=state_dict, max_batch=self.encode_batch, bank_slots=bank_slots,
-                             feat_slots=max(2 * self.encode_batch, 4), device=device)
+                             feat_slots=max(2 * self.encode_batch, 4), device=device, precision=precision)
         self.device = self.engine.device
         self.image_size = self.cfg["image_size"]
         self.num_maskmem = self.cfg["num_maskmem"]
@@ -64,6 +64,11 @@ class SAM2VideoPredictor:
             self._enc_stream = torch.cuda.Stream(device=self.device, priority=_prio)
         self.backend = "hip"
         self.debug_trace = None      # set to {} to record per-frame intermediates (parity tests)
+        # Feature-cache and memory-bank slots belong to the engine, so the allocators live here and inference states
+        # borrow from them: several states may be alive on one predictor (as in the reference, which keeps everything
+        # in `inference_state`) without aliasing each other's slots.  `reset_state` / `release_state` return them.
+        self._free_feat_slots = list(range(self.engine.feat_slots))
+        self._free_bank_slots = list(range(self.engine.bank_slots))
 
     # ------------------------------------------------------------------ backend switch (reference: speedup :45-145)
     def speedup(self, backend: str = "hip", use_cache: bool = True, model_root_path=None):
@@ -97,23 +102,42 @@ class SAM2VideoPredictor:
             "device": self.device, "offload_video_to_cpu": offload_video_to_cpu,
             "point_inputs_per_obj": {}, "mask_inputs_per_obj": {}, "obj_id_to_idx": OrderedDict(), "obj_idx_to_id": OrderedDict(), "obj_ids": [],
             "output_dict_per_obj": {}, "temp_output_dict_per_obj": {}, "frames_tracked_per_obj": {},
-            "feat_slot_of_frame": OrderedDict(), "free_feat_slots": list(range(self.engine.feat_slots)),
-            "free_bank_slots": list(range(self.engine.bank_slots)),
+            "feat_slot_of_frame": OrderedDict(),
             "feat_events": {},          # frame -> event recorded on the encoder stream (features still in flight)
+            "bank_slots_held": set(),   # memory-bank slots borrowed from the predictor
+            "stale_outputs": OrderedDict(),   # id(out) -> non-cond output no later frame attends to: recycled when the bank is full
         }
+        self._sync_encoder_stream()
         self._ensure_features(st, 0, forward=True)       # warm up the backbone like the reference (:204)
         return st
 
+    def _sync_encoder_stream(self):
+        """All encoder launches share one workspace: work of the caller's stream must not start an encoder pass (or reuse
+        feature slots) while a prefetch is still running on the encoder stream."""
+        if self._enc_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._enc_stream)
+
     def reset_state(self, st):
+        self._sync_encoder_stream()
         for d in list(st["output_dict_per_obj"].values()) + list(st["temp_output_dict_per_obj"].values()):
             for k in ("cond_frame_outputs", "non_cond_frame_outputs"):
                 for out in d[k].values():
                     self._free_bank(st, out)
                 d[k].clear()
+        st["stale_outputs"].clear()
         for k in ("point_inputs_per_obj", "mask_inputs_per_obj", "obj_id_to_idx", "obj_idx_to_id", "output_dict_per_obj",
                   "temp_output_dict_per_obj", "frames_tracked_per_obj"):
             st[k].clear()
         st["obj_ids"] = []
+
+    def release_state(self, st):
+        """Return every slot the state borrowed (feature cache too); the state must not be used afterwards."""
+        self.reset_state(st)
+        self._free_bank_slots.extend(st["bank_slots_held"])       # anything not reachable through the output dicts
+        st["bank_slots_held"].clear()
+        self._free_feat_slots.extend(st["feat_slot_of_frame"].values())
+        st["feat_slot_of_frame"].clear()
+        st["feat_events"].clear()
 
     def _obj_id_to_idx(self, st, obj_id):
         idx = st["obj_id_to_idx"].get(obj_id)
@@ -132,13 +156,26 @@ class SAM2VideoPredictor:
 
     # ------------------------------------------------------------------ slots
     def _alloc_bank(self, st) -> int:
-        if not st["free_bank_slots"]:
+        if not self._free_bank_slots:
+            # bank full: recycle the oldest output no later frame of the pass that produced it attends to.  It keeps its
+            # low-res mask; should a later request (reverse pass, re-interaction far behind the tracking head) select its
+            # memory, _select_memory raises instead of tracking without it.
+            while st["stale_outputs"] and not self._free_bank_slots:
+                _, out = st["stale_outputs"].popitem(last=False)
+                if out.get("slot") is not None:
+                    self._free_bank(st, out)
+                    out["has_mem"] = False
+                    out["recycled"] = True
+        if not self._free_bank_slots:
             raise RuntimeError("memory bank exhausted: raise bank_slots")
-        return st["free_bank_slots"].pop()
+        sl = self._free_bank_slots.pop()
+        st["bank_slots_held"].add(sl)
+        return sl
 
     def _free_bank(self, st, out):
         if out is not None and out.get("slot") is not None:
-            st["free_bank_slots"].append(out["slot"])
+            st["bank_slots_held"].discard(out["slot"])
+            self._free_bank_slots.append(out["slot"])
             out["slot"] = None
 
     def _encode_batch(self, st, start: int, forward: bool, side: bool):
@@ -149,11 +186,13 @@ class SAM2VideoPredictor:
         idxs = [t for t in range(start, start + step * self.encode_batch, step) if 0 <= t < T and t not in m]
         if not idxs:
             return
-        while len(st["free_feat_slots"]) < len(idxs):          # evict the oldest cached frames
+        while len(self._free_feat_slots) < len(idxs):          # evict the oldest cached frames of this state
+            if not m:
+                raise RuntimeError("feature cache exhausted by other inference states: release_state() them or raise encode_batch")
             t_old, sl = m.popitem(last=False)
             st["feat_events"].pop(t_old, None)
-            st["free_feat_slots"].append(sl)
-        slots = [st["free_feat_slots"].pop() for _ in idxs]
+            self._free_feat_slots.append(sl)
+        slots = [self._free_feat_slots.pop() for _ in idxs]
 
         def run():
             imgs = st["images"][idxs] if len(idxs) > 1 else st["images"][idxs[0]:idxs[0] + 1]
@@ -171,6 +210,7 @@ class SAM2VideoPredictor:
             for t in idxs:
                 st["feat_events"][t] = ev
         else:
+            self._sync_encoder_stream()          # a prefetch in flight uses the same encoder workspace
             run()
         for t, sl in zip(idxs, slots):
             m[t] = sl
@@ -389,6 +429,9 @@ class SAM2VideoPredictor:
             mems.append((t_pos, non_cond.get(prev)))
         n = 0
         for t_pos, out in mems:
+            if out is not None and out.get("recycled"):
+                raise RuntimeError("a memory frame this request attends to was recycled because the memory bank was full: "
+                                   "construct the predictor with a larger bank_slots")
             if out is None or not out["has_mem"]:
                 continue
             if n >= 8:
@@ -405,6 +448,9 @@ class SAM2VideoPredictor:
             if t < 0 or t >= num_frames:
                 break
             out = non_cond.get(t)
+            if out is not None and out.get("recycled"):
+                raise RuntimeError("an object pointer this request attends to was recycled because the memory bank was full: "
+                                   "construct the predictor with a larger bank_slots")
             if out is not None and out["slot"] is not None:
                 ptrs.append((t_diff, out))
         if len(ptrs) > 32:
@@ -416,12 +462,15 @@ class SAM2VideoPredictor:
         sel.ptr_tmax = float(max_ptrs - 1)
         return sel
 
-    def _release_stale(self, st, od, frame_idx: int, reverse: bool):
-        """Bank slots of non-conditioning frames that no later frame can attend to are recycled
-        (the reference keeps them for re-interaction; low-res masks are kept here too)."""
+    def _release_stale(self, st, obj_idx: int, od, frame_idx: int, reverse: bool):
+        """Non-conditioning outputs that no later frame of THIS pass can attend to become candidates for recycling.  Like the
+        reference they keep their memory (a reverse pass or a correction click far behind the tracking head needs it);
+        `_alloc_bank` takes their slots back, oldest first, only once the bank is full."""
         horizon = self.max_obj_ptrs_in_encoder + 1
-        for t in [t for t in od["non_cond_frame_outputs"] if (t > frame_idx + horizon if reverse else t < frame_idx - horizon)]:
-            self._free_bank(st, od["non_cond_frame_outputs"][t])
+        t = frame_idx + horizon + 1 if reverse else frame_idx - horizon - 1
+        out = od["non_cond_frame_outputs"].get(t)
+        if out is not None and out.get("slot") is not None:
+            st["stale_outputs"][id(out)] = out
 
     @torch.inference_mode()
     def propagate_in_video(self, inference_state, start_frame_idx=None, max_frame_num_to_track=None, reverse=False):
@@ -473,7 +522,7 @@ class SAM2VideoPredictor:
                     od = st["output_dict_per_obj"][obj_idx]
                     od["non_cond_frame_outputs"][frame_idx] = dict(slot=slot, pred_masks=outs["low_res_masks"],
                                                                    object_score_logits=outs["object_score_logits"], has_mem=True, is_pts=False)
-                    self._release_stale(st, od, frame_idx, reverse)
+                    self._release_stale(st, obj_idx, od, frame_idx, reverse)
                     per_obj[obj_idx] = outs["low_res_masks"]
             for obj_idx in range(len(st["obj_ids"])):
                 st["frames_tracked_per_obj"][obj_idx][frame_idx] = {"reverse": reverse}

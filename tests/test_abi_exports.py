@@ -21,7 +21,7 @@ def test_library_builds_and_exports_header_symbols():
     assert len(names) >= 20
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"declared in sam2mi.h but not exported: {missing}"
-    assert lib.sam2mi_abi_version() == 1
+    assert lib.sam2mi_abi_version() == 2
 
 
 def test_python_binding_lists_every_export():

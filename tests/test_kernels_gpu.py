@@ -1,6 +1,7 @@
 """GPU: single HIP kernels through the C ABI (sam2mi_debug_*) vs plain PyTorch fp32 on the same inputs.
 Operands are rounded to f16 on both sides, so the tolerance only has to cover accumulation order."""
 import math
+import os
 
 import pytest
 import torch
@@ -27,7 +28,7 @@ def r16(x):
     (300, 200, 144, 0, False), (4096, 1728, 576, 0, False), (16384, 432, 144, 1, True), (8, 256, 256, 2, False),
     (1000, 64, 160, 0, True), (4096, 4, 32, 0, False), (129, 65, 2304, 1, True), (4096, 576, 2304, 0, True),
 ])
-@pytest.mark.parametrize("hint", [0, 2, 5, 6, 10, 13, 14, 15, 16, 20])   # automatic (14: 16-wave 256x256, 15: 12-wave 256x192, 16: 128x192), 256x128, 64x64, persistent v3, 8-wave 128x128 / 128x64, 256x256 staggered (K % 64 == 0)
+@pytest.mark.parametrize("hint", [0, 5, 10, 13, 16])   # automatic, then the four production tiles forced: 64x64, 128x128, 128x64, 128x192
 def test_gemm(eng, M, N, K, act, res, hint):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
     A = r16(torch.randn(M, K, generator=g)).cuda()
@@ -136,6 +137,8 @@ def test_gemm_xs(eng, M, N, K, act, res):
 
 @pytest.mark.parametrize("M,K,res", [(4096, 2304, True), (1000, 576, True), (128, 128, False), (333, 1152, False)])
 def test_gemm_ks(eng, M, K, res):
+    if not os.environ.get("SAM2MI_EXPERIMENTAL"):
+        pytest.skip("gemm_ks.hip is only built with SAM2MI_EXPERIMENTAL=1 (measured equal to the tiled kernel, not shipped)")
     """Accumulator-stationary N = 576 GEMM (gemm_ks.hip; projection / fc2 of Hiera stage 3) vs fp64 PyTorch on f16-rounded
     operands: f32 output with bias and optional residual, ragged M."""
     N = 576

@@ -37,6 +37,79 @@ def test_oracle_batch_and_idempotence():
     assert np.array_equal(fill_holes_in_mask_scores(a, 8), a)    # filled pixels become foreground: nothing left to fill
 
 
+def _same_partition(a, b):
+    """Two labelings describe the same components iff the label pairs are in 1-1 correspondence."""
+    pairs = np.unique(np.stack([a.ravel(), b.ravel()], 1), axis=0)
+    return len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1]))
+
+
+def _adversarial_masks():
+    rs = np.random.RandomState(123)
+    out = []
+    for dens in (0.05, 0.3, 0.5, 0.6, 0.75, 0.95):                  # around the 8-connectivity percolation threshold too
+        out.append(rs.rand(64, 96) < dens)
+    yy, xx = np.mgrid[0:64, 0:64]
+    out.append((yy + xx) % 2 == 0)                                   # checkerboard: ONE component under 8-connectivity
+    out.append((yy % 2 == 0) & (xx % 2 == 0))                        # isolated pixels at block origins
+    out.append((yy % 2 == 1) & (xx % 2 == 1))                        # isolated pixels at the block corner the kernel never tests
+    out.append((yy % 4 == 1) & (xx % 4 == 2) | (yy % 4 == 2) & (xx % 4 == 1))     # anti-diagonal pairs across block borders
+    out.append(np.abs(yy - xx) <= 0)                                 # one long diagonal (corner contacts only)
+    out.append(np.abs(yy + xx - 63) <= 0)                            # anti-diagonal
+    sp = np.zeros((64, 64), bool)                                    # a spiral: one snake component with long union chains
+    y = x = 0
+    for step in range(62, 0, -4):
+        sp[y, x:x + step] = True; x += step
+        sp[y:y + step, x] = True; y += step
+        sp[y, x - step + 2:x + 1] = True; x -= step - 2
+        sp[y - step + 2:y + 1, x] = True; y -= step - 2
+    out.append(sp)
+    out.append(np.ones((2, 2), bool))
+    out.append(np.zeros((4, 6), bool))
+    out.append(np.ones((30, 2), bool))
+    return out
+
+
+def test_blockuf_restatement_equals_scipy_oracle():
+    """The pin for SURVEY 8 f-2: the CPU restatement of csrc/connected_components.cu (oracle/cc_blockuf.py) and the
+    scipy-based oracle the HIP kernel is held to (oracle/postproc.py) give the same partition and the same areas."""
+    from oracle import cc_blockuf, postproc
+    for m in _adversarial_masks():
+        la, ca = cc_blockuf.get_connected_components(m)
+        lb, cb = postproc.connected_components(m)
+        assert np.array_equal(la > 0, m) and np.array_equal(lb > 0, m)
+        assert np.array_equal(ca, cb), m.shape
+        assert _same_partition(la, lb), m.shape
+        roots = np.unique(la[la > 0]) - 1                            # a label is (block-origin index of the root) + 1
+        W = m.shape[1]
+        assert np.all((roots // W) % 2 == 0) and np.all((roots % W) % 2 == 0)
+
+
+def test_blockuf_fill_equals_scipy_fill_and_known_answers():
+    from oracle import cc_blockuf, postproc
+    m = _known_case()
+    for area in (1, 2, 8, 9, 63):
+        assert np.array_equal(cc_blockuf.fill_holes_in_mask_scores(m, area), postproc.fill_holes_in_mask_scores(m, area))
+    rs = np.random.RandomState(7)
+    for dens in (0.55, 0.8, 0.97):
+        s = np.where(rs.rand(2, 1, 128, 128) < dens, 1.0, -1.0).astype(np.float32) * (0.5 + rs.rand(2, 1, 128, 128).astype(np.float32))
+        s[0, 0, 5, 5] = 0.0                                          # score exactly 0 is background
+        for area in (1, 8, 40):
+            assert np.array_equal(cc_blockuf.fill_holes_in_mask_scores(s, area), postproc.fill_holes_in_mask_scores(s, area))
+
+
+def test_blockuf_rejects_odd_sizes_like_the_cuda_kernel():
+    """connected_components.cu:226-227 asserts even H and W; utils/misc.py:325-336 then skips the filling.  The scipy oracle
+    and the HIP kernel fill odd-sized masks too (a superset of the reference's behaviour; pred_masks are always 256x256)."""
+    from oracle import cc_blockuf, postproc
+    odd = -np.ones((37, 53), np.float32)
+    odd[3:30, 4:40] = 1.0
+    odd[10, 10] = -1.0
+    with pytest.raises(ValueError):
+        cc_blockuf.get_connected_components(odd <= 0)
+    assert np.array_equal(cc_blockuf.fill_holes_in_mask_scores(odd, 8), odd)          # the reference's failure path: unchanged
+    assert postproc.fill_holes_in_mask_scores(odd, 8)[10, 10] == np.float32(0.1)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("max_area", [1, 8, 63])
 def test_fill_holes_gpu_matches_oracle(max_area):

@@ -245,9 +245,9 @@ def test_remove_object_and_clear_prompts(predictor):
     assert len(alone) == 4
     for a, b in zip(alone, both):
         assert a.shape[0] == 1 and torch.equal(a, b[1:2])
-    free_before = len(st["free_bank_slots"])
+    free_before = len(predictor._free_bank_slots)
     _, ids3, vm = predictor.clear_all_prompts_in_frame(st, 0, 9)
-    assert list(ids3) == [9] and len(st["free_bank_slots"]) >= free_before
+    assert list(ids3) == [9] and len(predictor._free_bank_slots) >= free_before
     with pytest.raises(RuntimeError):                       # no conditioning frame left for object 9
         next(predictor.propagate_in_video(st))
     predictor.reset_state(st)
