@@ -2,7 +2,7 @@
 from /root/reference on seeded synthetic inputs and weights.  Container-only; the
 outputs (data, not code) are committed and travel to the GPU box.
 
-    python -m oracle.gen_golden [plugs] [video] [tiny] [interact] [reverse] [multi] [box] [long]
+    python -m oracle.gen_golden [plugs] [video] [tiny] [interact] [reverse] [multi] [box] [long] [opts]
 
 Weights: sam2_opt_amd.weights.synthetic_state_dict(cfg, seed=0)   (regenerated anywhere)
 Inputs : sam2_opt_amd.synthetic.*  with the seeds named below.
@@ -246,9 +246,14 @@ def _video_model(seed, num_frames, **kw):
 def gen_multi():
     """Multi-object tracking through the reference's per-object loop (sam2_video_predictor_official.py:691-725) and
     _consolidate_temp_output_across_obj / non-overlap logic: scenario A = objects 1 and 2 clicked on frame 0; scenario B adds
-    object 3 with its click on frame 2 (staggered prompts: on frames 0-1 object 3 is tracked from its FUTURE conditioning frame);
-    scenario C = scenario A with non_overlap_masks=True.  Per frame: the (num_obj,1,H,W) video-res masks (sampled) and every
-    object's low-res logits of frames 3 and 7 in full."""
+    object 3 with its click on frame 2 (staggered prompts) and propagates forward from frame 2, then in reverse from frame 2
+    back to 0 (on frames 1 and 0 object 3 is tracked from its conditioning frame 2; objects 1-2 pass their conditioning
+    frame 0); scenario C = scenario A with non_overlap_masks=True.  Per frame: the (num_obj,1,H,W) video-res masks (sampled)
+    and every object's low-res logits of frames 3 and 7 in full.
+    Not pinned here: propagating scenario B forward from frame 0.  Object 3 then has only a FUTURE conditioning frame, so
+    its memory holds no object pointers (P = 0) and the reference's fp32 torch path fails in RoPEAttention.v_proj with
+    "mat1 and mat2 must have the same dtype" (the bf16 memory is only promoted to f32 by the concatenation with the f32
+    pointers, sam2_base_official.py:964-965) - it needs the autocast the reference runs under on a GPU."""
     store = {}
     t0 = time.time()
     for tag, objs, kw in (("A", (1, 2), {}), ("B", (1, 2, 3), {}), ("C", (1, 2), {"non_overlap_masks": True})):
@@ -260,7 +265,8 @@ def gen_multi():
                                                      labels=np.array([1], np.int32))
             pack(store, f"{tag}/click{oid}/video_res_mask", vm, 16384)
             store[f"{tag}/click{oid}/obj_ids"] = np.array(ids, dtype=np.int64)
-        for fi, ids, vm in model.propagate_in_video(state):
+        start = 2 if tag == "B" else None
+        for fi, ids, vm in model.propagate_in_video(state, start_frame_idx=start):
             pack(store, f"{tag}/f{fi}/video_res_mask", vm, 16384)
             store[f"{tag}/f{fi}/obj_ids"] = np.array(ids, dtype=np.int64)
             if fi in (3, 7):
@@ -269,6 +275,10 @@ def gen_multi():
                     cur = od["cond_frame_outputs"].get(fi) or od["non_cond_frame_outputs"][fi]
                     store[f"{tag}/f{fi}/obj{k}/pred_masks"] = cur["pred_masks"].float().cpu().numpy()
             print("multi", tag, "frame", fi, time.time() - t0, flush=True)
+        if tag == "B":
+            for fi, ids, vm in model.propagate_in_video(state, start_frame_idx=2, reverse=True):
+                pack(store, f"{tag}/rev/f{fi}/video_res_mask", vm, 16384)
+                print("multi", tag, "reverse frame", fi, time.time() - t0, flush=True)
     np.savez_compressed(os.path.join(GOLD, "large_multi8.npz"), **store)
     print("multi done", time.time() - t0)
 
@@ -343,6 +353,39 @@ def gen_long():
     print("long done", time.time() - t0)
 
 
+OPTS_FRAMES = 12
+OPTS = dict(max_cond_frames_in_attn=2, memory_temporal_stride_for_eval=2, add_all_frames_to_correct_as_cond=True)
+OPTS_CLICKS = ((0, (512.0, 512.0)), (5, (530.0, 500.0)), (10, (500.0, 540.0)))
+
+
+@torch.inference_mode()
+def gen_opts():
+    """Non-default predictor / model options (sam2_video_predictor_official.py:24-40, sam2_base_official.py:39-41,:63):
+    max_cond_frames_in_attn=2 with three, later four, conditioning frames (select_closest_cond_frames; an unselected one is
+    attended to as a non-conditioning frame), memory_temporal_stride_for_eval=2, add_all_frames_to_correct_as_cond=True (the
+    correction click on tracked frame 7 turns it into a conditioning frame).  `clear_non_cond_mem_around_input` cannot be
+    recorded: the reference calls self._clear_obj_non_cond_mem_around_input (:632,:704), which it does not define."""
+    store = {}
+    t0 = time.time()
+    model = _video_model(16, OPTS_FRAMES, **OPTS)
+    state = model.init_state(video_path="synthetic")
+    for fr, pt in OPTS_CLICKS:
+        _, _, vm = model.add_new_points_or_box(state, frame_idx=fr, obj_id=1, points=np.array([pt], np.float32), labels=np.array([1], np.int32))
+        pack(store, f"click{fr}/video_res_mask", vm, 16384)
+    for fi, ids, vm in model.propagate_in_video(state):
+        pack(store, f"p1/f{fi}/video_res_mask", vm, 8192)
+        print("opts pass 1", fi, time.time() - t0, flush=True)
+    _, _, vm = model.add_new_points_or_box(state, frame_idx=7, obj_id=1, points=np.array([[600.0, 420.0]], np.float32), labels=np.array([0], np.int32))
+    pack(store, "fix7/video_res_mask", vm, 16384)
+    for fi, ids, vm in model.propagate_in_video(state, start_frame_idx=6):
+        pack(store, f"p2/f{fi}/video_res_mask", vm, 8192)
+        print("opts pass 2", fi, time.time() - t0, flush=True)
+    od = state["output_dict_per_obj"][0]
+    store["cond_frames"] = np.array(sorted(od["cond_frame_outputs"]), dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "large_opts12.npz"), **store)
+    print("opts done", time.time() - t0, sorted(od["cond_frame_outputs"]))
+
+
 @torch.inference_mode()
 def gen_tiny():
     """BASELINE.json configs[0]: SAM2.1-hiera-tiny image predictor, one 1024^2 frame, torch backend on the CPU - the
@@ -386,3 +429,5 @@ if __name__ == "__main__":
         gen_box()
     if "long" in which:
         gen_long()
+    if "opts" in which:
+        gen_opts()

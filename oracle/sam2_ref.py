@@ -486,18 +486,44 @@ def encode_new_memory(pix_feat, high_res_masks, obj_logits, is_mask_from_pts, sd
 
 
 # ----------------------------------------------------------------------------- memory bank assembly (a8)
-def assemble_memory(frame_idx, cond_outputs, non_cond_outputs, num_frames, sd, cfg, reverse=False):
+def closest_cond_frames(frame_idx, cond_outputs, max_num):
+    """select_closest_cond_frames (modeling/sam2_utils.py:19-61)."""
+    if max_num == -1 or len(cond_outputs) <= max_num:
+        return cond_outputs, {}
+    assert max_num >= 2
+    chosen = {}
+    earlier = [t for t in cond_outputs if t < frame_idx]
+    later = [t for t in cond_outputs if t >= frame_idx]
+    if earlier:
+        chosen[max(earlier)] = cond_outputs[max(earlier)]
+    if later:
+        chosen[min(later)] = cond_outputs[min(later)]
+    rest = sorted([t for t in cond_outputs if t not in chosen], key=lambda t: abs(t - frame_idx))
+    for t in rest[: max_num - len(chosen)]:
+        chosen[t] = cond_outputs[t]
+    return chosen, {t: o for t, o in cond_outputs.items() if t not in chosen}
+
+
+def assemble_memory(frame_idx, cond_outputs, non_cond_outputs, num_frames, sd, cfg, reverse=False, max_cond_frames_in_attn=-1, stride=1):
     """SAM2Base._prepare_memory_conditioned_features step 1 (sam2_base_official.py:823-946),
-    forward or reverse tracking, stride 1, max_cond_frames_in_attn=-1.  Outputs dicts hold
-    maskmem_features (1,64,64,64) [bf16-rounded], maskmem_pos_enc (1,64,64,64), obj_ptr (1,256).
+    forward or reverse tracking, with max_cond_frames_in_attn (:828-832) and memory_temporal_stride_for_eval (:838-868).
+    Outputs dicts hold maskmem_features (1,64,64,64) [bf16-rounded], maskmem_pos_enc (1,64,64,64), obj_ptr (1,256).
     Returns the six plug inputs (without curr/curr_pos): memory (L,4096,1,64), memory_pos,
     memory_exclude (P,1,64), memory_pos_exclude."""
     nm = cfg["num_maskmem"]
     C, M = cfg["d_model"], cfg["mem_dim"]
+    all_cond = cond_outputs
+    cond_outputs, unselected = closest_cond_frames(frame_idx, all_cond, max_cond_frames_in_attn)
     t_pos_and_prevs = [(0, out) for out in cond_outputs.values()]
     for t_pos in range(1, nm):
         t_rel = nm - t_pos
-        t_pos_and_prevs.append((t_pos, non_cond_outputs.get(frame_idx + t_rel if reverse else frame_idx - t_rel, None)))
+        if t_rel == 1:
+            prev_idx = frame_idx + 1 if reverse else frame_idx - 1
+        elif reverse:
+            prev_idx = -(-(frame_idx + 2) // stride) * stride + (t_rel - 2) * stride
+        else:
+            prev_idx = ((frame_idx - 2) // stride) * stride - (t_rel - 2) * stride
+        t_pos_and_prevs.append((t_pos, non_cond_outputs.get(prev_idx, unselected.get(prev_idx, None))))
     mems, mposs = [], []
     for t_pos, prev in t_pos_and_prevs:
         if prev is None:
@@ -513,7 +539,7 @@ def assemble_memory(frame_idx, cond_outputs, non_cond_outputs, num_frames, sd, c
         t = frame_idx + t_diff if reverse else frame_idx - t_diff
         if t < 0 or t >= num_frames:
             break
-        out = non_cond_outputs.get(t, None)
+        out = non_cond_outputs.get(t, unselected.get(t, None))
         if out is not None:
             pos_and_ptrs.append((t_diff, out["obj_ptr"]))
     memory = torch.stack(mems, dim=0)            # (L,4096,1,64)

@@ -13,7 +13,8 @@ Differences from the reference, all deliberate:
     the tracking state; the reference encodes one frame at a time;
   * `fill_hole_area` defaults to 0 (the goldens were recorded from the reference without its CUDA extension, where the
     step is silently skipped, utils/misc.py:321-336); pass 8 (build_sam.py:129) to fill holes on the device;
-  * `clear_non_cond_mem_around_input` and `add_all_frames_to_correct_as_cond` are fixed at their defaults (False).
+  * `clear_non_cond_mem_around_input`, `add_all_frames_to_correct_as_cond`, `max_cond_frames_in_attn` and
+    `memory_temporal_stride_for_eval` are constructor options with the reference's defaults (False, False, -1, 1).
 """
 from __future__ import annotations
 
@@ -24,6 +25,7 @@ import numpy as np
 import torch
 
 from .config import get_config
+from .memory_select import select_memory
 from .native import Engine, MemSelect
 from .synthetic import normalize_frames
 
@@ -31,7 +33,9 @@ from .synthetic import normalize_frames
 class SAM2VideoPredictor:
     def __init__(self, model: str = "large", state_dict=None, ckpt_path: Optional[str] = None, device=None,
                  encode_batch: int = 8, bank_slots: int = 384, fill_hole_area: int = 0, non_overlap_masks: bool = False,
-                 overlap_encode: bool = True, precision: str = "f16"):
+                 overlap_encode: bool = True, precision: str = "f16", clear_non_cond_mem_around_input: bool = False,
+                 add_all_frames_to_correct_as_cond: bool = False, max_cond_frames_in_attn: int = -1,
+                 memory_temporal_stride_for_eval: int = 1):
         self.cfg = get_config(model)
         if state_dict is None and ckpt_path is not None:
             # same contract as build_sam._load_checkpoint (build_sam.py:164-174)
@@ -47,6 +51,11 @@ class SAM2VideoPredictor:
         self.max_obj_ptrs_in_encoder = self.cfg["max_obj_ptrs_in_encoder"]
         self.fill_hole_area = fill_hole_area
         self.non_overlap_masks = non_overlap_masks
+        # predictor / model options of the reference (sam2_video_predictor_official.py:24-40, sam2_base_official.py:39-41,:63)
+        self.clear_non_cond_mem_around_input = clear_non_cond_mem_around_input
+        self.add_all_frames_to_correct_as_cond = add_all_frames_to_correct_as_cond
+        self.max_cond_frames_in_attn = max_cond_frames_in_attn
+        self.memory_temporal_stride_for_eval = memory_temporal_stride_for_eval
         self.engine.set_fill_hole_area(fill_hole_area)       # 0 = off; > 0: holes filled on the device (postproc.hip)
         # The image encoder of the NEXT batch of frames runs on its own HIP stream beside the tracking of the current
         # batch: the tracking path is a chain of small latency-bound kernels (M = 4096 GEMMs, 8-token decoder ops) that
@@ -69,6 +78,9 @@ class SAM2VideoPredictor:
         # in `inference_state`) without aliasing each other's slots.  `reset_state` / `release_state` return them.
         self._free_feat_slots = list(range(self.engine.feat_slots))
         self._free_bank_slots = list(range(self.engine.bank_slots))
+        # frame features are recomputable, so the feature cache is ONE least-recently-encoded list over all live states:
+        # (id(state), frame) -> state; a state that needs slots evicts the oldest entry, whichever state it belongs to
+        self._feat_lru = OrderedDict()
 
     # ------------------------------------------------------------------ backend switch (reference: speedup :45-145)
     def speedup(self, backend: str = "hip", use_cache: bool = True, model_root_path=None):
@@ -135,7 +147,9 @@ class SAM2VideoPredictor:
         self.reset_state(st)
         self._free_bank_slots.extend(st["bank_slots_held"])       # anything not reachable through the output dicts
         st["bank_slots_held"].clear()
-        self._free_feat_slots.extend(st["feat_slot_of_frame"].values())
+        for t, sl in st["feat_slot_of_frame"].items():
+            self._feat_lru.pop((id(st), t), None)
+            self._free_feat_slots.append(sl)
         st["feat_slot_of_frame"].clear()
         st["feat_events"].clear()
 
@@ -155,19 +169,26 @@ class SAM2VideoPredictor:
         return idx
 
     # ------------------------------------------------------------------ slots
-    def _alloc_bank(self, st) -> int:
+    def _alloc_bank(self, st, protect=()) -> int:
+        """A free memory-bank slot.  `protect`: slots the pending request reads (its MemSelect) - never recycled for it."""
         if not self._free_bank_slots:
             # bank full: recycle the oldest output no later frame of the pass that produced it attends to.  It keeps its
             # low-res mask; should a later request (reverse pass, re-interaction far behind the tracking head) select its
             # memory, _select_memory raises instead of tracking without it.
-            while st["stale_outputs"] and not self._free_bank_slots:
-                _, out = st["stale_outputs"].popitem(last=False)
-                if out.get("slot") is not None:
-                    self._free_bank(st, out)
-                    out["has_mem"] = False
-                    out["recycled"] = True
+            for key in list(st["stale_outputs"]):
+                out = st["stale_outputs"][key]
+                if out.get("slot") is None:
+                    del st["stale_outputs"][key]
+                    continue
+                if out["slot"] in protect:
+                    continue
+                del st["stale_outputs"][key]
+                self._free_bank(st, out)
+                out["has_mem"] = False
+                out["recycled"] = True
+                break
         if not self._free_bank_slots:
-            raise RuntimeError("memory bank exhausted: raise bank_slots")
+            raise RuntimeError("memory bank exhausted: raise bank_slots (or release_state() inference states no longer in use)")
         sl = self._free_bank_slots.pop()
         st["bank_slots_held"].add(sl)
         return sl
@@ -186,12 +207,10 @@ class SAM2VideoPredictor:
         idxs = [t for t in range(start, start + step * self.encode_batch, step) if 0 <= t < T and t not in m]
         if not idxs:
             return
-        while len(self._free_feat_slots) < len(idxs):          # evict the oldest cached frames of this state
-            if not m:
-                raise RuntimeError("feature cache exhausted by other inference states: release_state() them or raise encode_batch")
-            t_old, sl = m.popitem(last=False)
-            st["feat_events"].pop(t_old, None)
-            self._free_feat_slots.append(sl)
+        while len(self._free_feat_slots) < len(idxs):          # evict the oldest cached frames (of any state)
+            (_, t_old), st_old = self._feat_lru.popitem(last=False)
+            self._free_feat_slots.append(st_old["feat_slot_of_frame"].pop(t_old))
+            st_old["feat_events"].pop(t_old, None)
         slots = [self._free_feat_slots.pop() for _ in idxs]
 
         def run():
@@ -214,6 +233,7 @@ class SAM2VideoPredictor:
             run()
         for t, sl in zip(idxs, slots):
             m[t] = sl
+            self._feat_lru[(id(st), t)] = st
 
     def _ensure_features(self, st, frame_idx: int, forward: bool = True) -> int:
         """Feature-cache slot of `frame_idx`; on a miss encode a batch of frames starting there
@@ -265,13 +285,15 @@ class SAM2VideoPredictor:
         # top of its memory-conditioned features (sam2_video_predictor_official.py:333-346)
         tracked = st["frames_tracked_per_obj"][obj_idx].get(frame_idx)
         is_init = tracked is None
-        key = "cond_frame_outputs" if is_init else "non_cond_frame_outputs"        # add_all_frames_to_correct_as_cond = False
+        # an output is a conditioning one if the frame is an initial conditioning frame or every corrected frame counts (:348-350)
+        key = "cond_frame_outputs" if (is_init or self.add_all_frames_to_correct_as_cond) else "non_cond_frame_outputs"
         od, td = st["output_dict_per_obj"][obj_idx], st["temp_output_dict_per_obj"][obj_idx]
         # the previous prediction on this frame, if any, goes in as a mask prompt (clamped; :352-366)
         prev = td[key].get(frame_idx) or od["cond_frame_outputs"].get(frame_idx) or od["non_cond_frame_outputs"].get(frame_idx)
         prev_logits = torch.clamp(prev["pred_masks"], -32.0, 32.0).contiguous() if prev is not None else None
         feat = self._ensure_features(st, frame_idx)
-        slot = self._alloc_bank(st)
+        sel = None if is_init else self._select_memory(od, frame_idx, st["num_frames"], tracked["reverse"])    # may raise: before any slot is taken
+        slot = self._alloc_bank(st, protect=() if sel is None else _sel_slots(sel))
         n = len(lab)
         # _use_multimask (sam2_base_official.py:1181-1189): only on initial conditioning frames (or while tracking), 1 point
         multimask = self.cfg["multimask_min_pt_num"] <= n <= self.cfg["multimask_max_pt_num"]
@@ -281,7 +303,6 @@ class SAM2VideoPredictor:
         if is_init:
             self.engine.video_click(feat, pts, lab, multimask, slot, outs, mask_logits=prev_logits)
         else:
-            sel = self._select_memory(od, frame_idx, st["num_frames"], tracked["reverse"])
             self.engine.video_track(feat, sel, slot, False, outs, points=pts, labels=lab, multimask=multimask, mask_logits=prev_logits)
         self._free_bank(st, td[key].pop(frame_idx, None))
         td[key][frame_idx] = dict(slot=slot, pred_masks=low, object_score_logits=score, has_mem=False, is_pts=True)
@@ -307,7 +328,7 @@ class SAM2VideoPredictor:
         st["mask_inputs_per_obj"][obj_idx][frame_idx] = m
         st["point_inputs_per_obj"][obj_idx].pop(frame_idx, None)
         is_init = frame_idx not in st["frames_tracked_per_obj"][obj_idx]
-        key = "cond_frame_outputs" if is_init else "non_cond_frame_outputs"
+        key = "cond_frame_outputs" if (is_init or self.add_all_frames_to_correct_as_cond) else "non_cond_frame_outputs"
         td = st["temp_output_dict_per_obj"][obj_idx]
         feat = self._ensure_features(st, frame_idx)
         slot = self._alloc_bank(st)
@@ -411,6 +432,8 @@ class SAM2VideoPredictor:
                         out["has_mem"] = True
                     self._free_bank(st, od[key].get(t))
                     od[key][t] = out
+                    if self.clear_non_cond_mem_around_input:
+                        self._clear_obj_non_cond_mem_around_input(st, t, obj_idx)
                 td[key].clear()
             if len(od["cond_frame_outputs"]) == 0:
                 raise RuntimeError(f"No input points or masks are provided for object id {st['obj_idx_to_id'][obj_idx]}; "
@@ -418,44 +441,43 @@ class SAM2VideoPredictor:
             for t in od["cond_frame_outputs"]:
                 self._free_bank(st, od["non_cond_frame_outputs"].pop(t, None))
 
+    def _clear_obj_non_cond_mem_around_input(self, st, frame_idx: int, obj_idx: int):
+        """Drop one object's non-conditioning memories within memory_temporal_stride * num_maskmem frames of an interacted
+        frame.  The reference calls a method of this name (sam2_video_predictor_official.py:632,:704) but only defines the
+        all-object `_clear_non_cond_mem_around_input` (:1062-1080), so its own option raises AttributeError; this is that
+        method's body for one object (what upstream SAM 2 does)."""
+        r = self.memory_temporal_stride_for_eval
+        nc = st["output_dict_per_obj"][obj_idx]["non_cond_frame_outputs"]
+        for t in range(frame_idx - r * self.num_maskmem, frame_idx + r * self.num_maskmem + 1):
+            self._free_bank(st, nc.pop(t, None))
+
     def _select_memory(self, od, frame_idx: int, num_frames: int, reverse: bool) -> MemSelect:
-        """SAM2Base._prepare_memory_conditioned_features step 1 (sam2_base_official.py:823-946)."""
+        """SAM2Base._prepare_memory_conditioned_features step 1 (sam2_base_official.py:823-946): the selection itself is
+        sam2_opt_amd.memory_select.select_memory; here its outputs become bank-slot lists for the device."""
+        mems, ptrs, max_ptrs = select_memory(od["cond_frame_outputs"], od["non_cond_frame_outputs"], frame_idx, num_frames, reverse,
+                                             self.num_maskmem, self.max_obj_ptrs_in_encoder, self.max_cond_frames_in_attn,
+                                             self.memory_temporal_stride_for_eval)
         sel = MemSelect()
-        cond, non_cond = od["cond_frame_outputs"], od["non_cond_frame_outputs"]
-        mems = [(0, out) for out in cond.values()]                   # max_cond_frames_in_attn = -1: all of them
-        for t_pos in range(1, self.num_maskmem):
-            t_rel = self.num_maskmem - t_pos
-            prev = frame_idx + t_rel if reverse else frame_idx - t_rel          # stride 1 (:843-864)
-            mems.append((t_pos, non_cond.get(prev)))
         n = 0
         for t_pos, out in mems:
-            if out is not None and out.get("recycled"):
+            if out.get("recycled"):
                 raise RuntimeError("a memory frame this request attends to was recycled because the memory bank was full: "
                                    "construct the predictor with a larger bank_slots")
-            if out is None or not out["has_mem"]:
+            if not out["has_mem"]:
                 continue
             if n >= 8:
-                raise NotImplementedError("more than 8 spatial memories (too many conditioning frames)")
+                raise NotImplementedError("more than 8 spatial memories: lower max_cond_frames_in_attn (the reference's TensorRT "
+                                          "engines take at most 7, sam2_video_predictor_official.py:116-138)")
             sel.mem_slot[n] = out["slot"]
             sel.mem_tpos[n] = self.num_maskmem - t_pos - 1
             n += 1
         sel.num_mem = n
-        max_ptrs = min(num_frames, self.max_obj_ptrs_in_encoder)
-        sign = -1 if reverse else 1
-        ptrs = [((frame_idx - t) * sign, out) for t, out in cond.items() if (t >= frame_idx if reverse else t <= frame_idx)]
-        for t_diff in range(1, max_ptrs):
-            t = frame_idx + t_diff if reverse else frame_idx - t_diff
-            if t < 0 or t >= num_frames:
-                break
-            out = non_cond.get(t)
-            if out is not None and out.get("recycled"):
-                raise RuntimeError("an object pointer this request attends to was recycled because the memory bank was full: "
-                                   "construct the predictor with a larger bank_slots")
-            if out is not None and out["slot"] is not None:
-                ptrs.append((t_diff, out))
         if len(ptrs) > 32:
             raise NotImplementedError("more than 32 object pointers")
         for i, (dt, out) in enumerate(ptrs):
+            if out.get("recycled") or out["slot"] is None:
+                raise RuntimeError("an object pointer this request attends to was recycled because the memory bank was full: "
+                                   "construct the predictor with a larger bank_slots")
             sel.ptr_slot[i] = out["slot"]
             sel.ptr_dt[i] = float(dt)
         sel.num_ptr = len(ptrs)
@@ -494,6 +516,8 @@ class SAM2VideoPredictor:
                 od = st["output_dict_per_obj"][obj_idx]
                 if frame_idx in od["cond_frame_outputs"]:
                     per_obj[obj_idx] = od["cond_frame_outputs"][frame_idx]["pred_masks"]
+                    if self.clear_non_cond_mem_around_input:
+                        self._clear_obj_non_cond_mem_around_input(st, frame_idx, obj_idx)
                 else:
                     todo.append(obj_idx)
             if todo:
@@ -506,7 +530,7 @@ class SAM2VideoPredictor:
                     od = st["output_dict_per_obj"][obj_idx]
                     sels.append(self._select_memory(od, frame_idx, num_frames, reverse))
                     self._free_bank(st, od["non_cond_frame_outputs"].pop(frame_idx, None))
-                    slots.append(self._alloc_bank(st))
+                    slots.append(self._alloc_bank(st, protect={sl for s_ in sels for sl in _sel_slots(s_)}))
                     outs = dict(low_res_masks=self.engine.new(1, 1, 256, 256), object_score_logits=self.engine.new(1, 1))
                     if self.debug_trace is not None:
                         outs.update(pix_feat=self.engine.new(4096, 1, 256), ious=self.engine.new(1, 3), obj_ptr=self.engine.new(1, 256),
@@ -528,6 +552,10 @@ class SAM2VideoPredictor:
                 st["frames_tracked_per_obj"][obj_idx][frame_idx] = {"reverse": reverse}
             low_all = torch.cat(per_obj, dim=0) if len(per_obj) > 1 else per_obj[0]
             yield frame_idx, st["obj_ids"], self._video_res(st, low_all)
+
+
+def _sel_slots(sel: MemSelect):
+    return {sel.mem_slot[i] for i in range(sel.num_mem)} | {sel.ptr_slot[i] for i in range(sel.num_ptr)}
 
 
 def _load_jpeg_folder(path, cfg):

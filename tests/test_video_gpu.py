@@ -251,3 +251,190 @@ def test_remove_object_and_clear_prompts(predictor):
     with pytest.raises(RuntimeError):                       # no conditioning frame left for object 9
         next(predictor.propagate_in_video(st))
     predictor.reset_state(st)
+
+
+def _golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+
+
+class _Worst:
+    """Running worst case of (max-abs / max|ref|, rel L2, binarised disagreement) against sampled golden tensors."""
+
+    def __init__(self, g, tol=(5e-3, 5e-3, 2e-3)):
+        self.g, self.tol, self.w = g, tol, [0.0, 0.0, 0.0]
+
+    def chk(self, name, t):
+        got, ref = _sample(t, self.g, name)
+        m = float(np.abs(got - ref).max() / np.abs(ref).max())
+        l2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        dis = float(((got > 0) != (ref > 0)).mean())
+        self.w = [max(a, b) for a, b in zip(self.w, (m, l2, dis))]
+        assert m <= self.tol[0] and l2 <= self.tol[1] and dis <= self.tol[2], (name, m, l2, dis)
+
+    def full(self, name, t):
+        got, ref = t.detach().float().cpu().numpy(), self.g[name]
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        m = float(np.abs(got - ref).max() / np.abs(ref).max())
+        l2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        dis = float(((got > 0) != (ref > 0)).mean())
+        self.w = [max(a, b) for a, b in zip(self.w, (m, l2, dis))]
+        assert m <= self.tol[0] and l2 <= self.tol[1] and dis <= self.tol[2], (name, m, l2, dis)
+
+
+@pytest.mark.parametrize("tag", ["A", "B", "C"])
+def test_multi_object_matches_reference_golden(sd_large, tag):
+    """SURVEY 8 f-4 pinned to the REAL reference (tests/golden/large_multi8.npz, oracle/gen_golden.py::gen_multi): the batched
+    object pass (sam2mi_video_track_batch) against the reference's per-object B = 1 loop (sam2_video_predictor_official.py:
+    691-725).  A: two objects clicked on frame 0.  B: a third object clicked on frame 2, forward from frame 2, then reverse
+    from frame 2 to 0.  C: A with non_overlap_masks (SAM2Base._apply_non_overlapping_constraints)."""
+    from oracle.gen_golden import MULTI_CLICKS, MULTI_FRAMES
+    from sam2_opt_amd.synthetic import synthetic_frames_u8
+    from sam2_opt_amd.video_predictor import SAM2VideoPredictor
+    g = _golden("large_multi8.npz")
+    objs = (1, 2, 3) if tag == "B" else (1, 2)
+    pred = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4, non_overlap_masks=(tag == "C"))
+    try:
+        w = _Worst(g)
+        st = pred.init_state(frames_u8=synthetic_frames_u8(seed=8, num_frames=MULTI_FRAMES), video_height=1024, video_width=1024)
+        for oid in objs:
+            fr, pt = MULTI_CLICKS[oid]
+            _, ids, vm = pred.add_new_points_or_box(st, fr, oid, points=np.array([pt], np.float32), labels=np.array([1], np.int32))
+            assert list(ids) == list(g[f"{tag}/click{oid}/obj_ids"])
+            w.chk(f"{tag}/click{oid}/video_res_mask", vm)
+        seen = []
+        for t, ids, vm in pred.propagate_in_video(st, start_frame_idx=2 if tag == "B" else None):
+            assert list(ids) == list(g[f"{tag}/f{t}/obj_ids"]) and vm.shape[0] == len(objs)
+            w.chk(f"{tag}/f{t}/video_res_mask", vm)
+            if t in (3, 7):
+                for k in range(len(objs)):
+                    od = st["output_dict_per_obj"][k]
+                    cur = od["cond_frame_outputs"].get(t) or od["non_cond_frame_outputs"][t]
+                    w.full(f"{tag}/f{t}/obj{k}/pred_masks", cur["pred_masks"])
+            seen.append(t)
+        assert seen == list(range(2 if tag == "B" else 0, MULTI_FRAMES))
+        if tag == "B":
+            rev = []
+            for t, ids, vm in pred.propagate_in_video(st, start_frame_idx=2, reverse=True):
+                w.chk(f"{tag}/rev/f{t}/video_res_mask", vm)
+                rev.append(t)
+            assert rev == [2, 1, 0]
+        print(f"[parity] multi-object scenario {tag} vs reference: max_rel={w.w[0]:.3e} l2={w.w[1]:.3e} pixel disagreement={w.w[2]:.3e}", flush=True)
+    finally:
+        pred.release()
+
+
+@pytest.mark.parametrize("tag", ["box", "boxpt"])
+def test_box_prompt_matches_reference_golden(predictor, tag):
+    """Box prompts (labels 2 / 3: sam2_video_predictor_official.py:300-316, prompt_encoder.py:124-166) alone and together with
+    a positive click, vs the REAL reference (tests/golden/large_box4.npz)."""
+    from oracle.gen_golden import BOX
+    from sam2_opt_amd.synthetic import synthetic_frames_u8
+    g = _golden("large_box4.npz")
+    w = _Worst(g)
+    st = predictor.init_state(frames_u8=synthetic_frames_u8(seed=12, num_frames=4), video_height=1024, video_width=1024)
+    pts = None if tag == "box" else np.array([[500.0, 600.0]], np.float32)
+    _, ids, vm = predictor.add_new_points_or_box(st, 0, 1, box=np.array(BOX, np.float32), points=pts,
+                                                 labels=None if pts is None else np.array([1], np.int32))
+    w.chk(f"{tag}/click/video_res_mask", vm)
+    cur = st["temp_output_dict_per_obj"][0]["cond_frame_outputs"][0]
+    w.full(f"{tag}/click/pred_masks", cur["pred_masks"])
+    n = 0
+    for t, _, vm in predictor.propagate_in_video(st):
+        w.chk(f"{tag}/f{t}/video_res_mask", vm)
+        n += 1
+    assert n == 4
+    print(f"[parity] box prompt ({tag}) vs reference: max_rel={w.w[0]:.3e} l2={w.w[1]:.3e} pixel disagreement={w.w[2]:.3e}", flush=True)
+    predictor.release_state(st)
+
+
+def test_long_clip_mid_click_forward_reverse_correction(sd_large):
+    """ADVICE r01 (stale memory slots): a 32-frame clip, click on frame 16, forward to the end, reverse back to frame 0 (frame 15
+    attends to the FORWARD pass's memories of frames 17..22), then a correction click on frame 5 - far behind the forward
+    tracking head - and re-tracking of frames 6..9; every mask vs the REAL reference (tests/golden/large_long32.npz).  A second
+    predictor with a tiny bank (24 slots) shows the recycling path: the forward pass recycles old frames, and the reverse
+    pass - which needs them - fails with a clear error instead of tracking without memory."""
+    from oracle.gen_golden import LONG_CLICK_FRAME, LONG_FRAMES
+    from sam2_opt_amd.synthetic import synthetic_frames_u8
+    from sam2_opt_amd.video_predictor import SAM2VideoPredictor
+    g = _golden("large_long32.npz")
+    u8 = synthetic_frames_u8(seed=14, num_frames=LONG_FRAMES)
+    click = dict(points=np.array([CLICK], np.float32), labels=np.array([1], np.int32))
+    pred = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4)
+    try:
+        w = _Worst(g)
+        st = pred.init_state(frames_u8=u8, video_height=1024, video_width=1024)
+        _, _, vm = pred.add_new_points_or_box(st, LONG_CLICK_FRAME, 1, **click)
+        w.chk("click/video_res_mask", vm)
+        fwd = [t for t, _, vm in pred.propagate_in_video(st) if w.chk(f"fwd/f{t}/video_res_mask", vm) is None]
+        assert fwd == list(range(LONG_CLICK_FRAME, LONG_FRAMES))
+        rev = [t for t, _, vm in pred.propagate_in_video(st, reverse=True) if w.chk(f"rev/f{t}/video_res_mask", vm) is None]
+        assert rev == list(range(LONG_CLICK_FRAME, -1, -1))
+        _, _, vm = pred.add_new_points_or_box(st, 5, 1, points=np.array([[420.0, 640.0]], np.float32), labels=np.array([0], np.int32))
+        w.chk("fix5/video_res_mask", vm)
+        fix = [t for t, _, vm in pred.propagate_in_video(st, start_frame_idx=6, max_frame_num_to_track=3) if w.chk(f"fix/f{t}/video_res_mask", vm) is None]
+        assert fix == [6, 7, 8, 9]
+        print(f"[parity] 32-frame mid-clip click / reverse / correction vs reference: max_rel={w.w[0]:.3e} l2={w.w[1]:.3e} "
+              f"pixel disagreement={w.w[2]:.3e}", flush=True)
+    finally:
+        pred.release()
+    small = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4, bank_slots=24)
+    try:
+        st = small.init_state(frames_u8=u8, video_height=1024, video_width=1024)
+        small.add_new_points_or_box(st, 2, 1, **click)
+        n = sum(1 for _ in small.propagate_in_video(st))              # 30 tracked frames through 24 slots: old ones recycled
+        assert n == LONG_FRAMES - 2
+        with pytest.raises(RuntimeError, match="recycled"):
+            small.add_new_points_or_box(st, 8, 1, points=np.array([[420.0, 640.0]], np.float32), labels=np.array([0], np.int32))
+    finally:
+        small.release()
+
+
+def test_early_stop_then_click_on_uncached_frame(sd_large):
+    """ADVICE r01 (encoder-stream race): stop propagation early (a prefetch of the next frames is still in flight on the encoder
+    stream), then click on a far, uncached frame - the miss path must wait for the prefetch before it reuses the shared
+    encoder workspace.  Bit-equal to a predictor without the encoder stream."""
+    from sam2_opt_amd.synthetic import synthetic_frames_u8
+    from sam2_opt_amd.video_predictor import SAM2VideoPredictor
+    u8 = synthetic_frames_u8(seed=15, num_frames=20)
+    outs = []
+    for overlap in (True, False):
+        p = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4, overlap_encode=overlap)
+        try:
+            st = p.init_state(frames_u8=u8, video_height=1024, video_width=1024)
+            p.add_new_points_or_box(st, 0, 1, points=np.array([CLICK], np.float32), labels=np.array([1], np.int32))
+            a = [vm.clone() for _, _, vm in p.propagate_in_video(st, max_frame_num_to_track=2)]
+            _, _, vm = p.add_new_points_or_box(st, 17, 2, points=np.array([[300.0, 700.0]], np.float32), labels=np.array([1], np.int32))
+            st2 = p.init_state(frames_u8=u8[::-1].copy(), video_height=1024, video_width=1024)      # a second state while the first is alive
+            _, _, vm2 = p.add_new_points_or_box(st2, 3, 1, points=np.array([CLICK], np.float32), labels=np.array([1], np.int32))
+            outs.append(a + [vm.clone(), vm2.clone()])
+        finally:
+            p.release()
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+
+
+def test_predictor_options_match_reference_golden(sd_large):
+    """max_cond_frames_in_attn=2 (three, then four conditioning frames), memory_temporal_stride_for_eval=2 and
+    add_all_frames_to_correct_as_cond=True vs the REAL reference built with the same options (tests/golden/large_opts12.npz)."""
+    from oracle.gen_golden import OPTS, OPTS_CLICKS, OPTS_FRAMES
+    from sam2_opt_amd.synthetic import synthetic_frames_u8
+    from sam2_opt_amd.video_predictor import SAM2VideoPredictor
+    g = _golden("large_opts12.npz")
+    pred = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4, **OPTS)
+    try:
+        w = _Worst(g)
+        st = pred.init_state(frames_u8=synthetic_frames_u8(seed=16, num_frames=OPTS_FRAMES), video_height=1024, video_width=1024)
+        for fr, pt in OPTS_CLICKS:
+            _, _, vm = pred.add_new_points_or_box(st, fr, 1, points=np.array([pt], np.float32), labels=np.array([1], np.int32))
+            w.chk(f"click{fr}/video_res_mask", vm)
+        p1 = [t for t, _, vm in pred.propagate_in_video(st) if w.chk(f"p1/f{t}/video_res_mask", vm) is None]
+        assert p1 == list(range(OPTS_FRAMES))
+        _, _, vm = pred.add_new_points_or_box(st, 7, 1, points=np.array([[600.0, 420.0]], np.float32), labels=np.array([0], np.int32))
+        w.chk("fix7/video_res_mask", vm)
+        p2 = [t for t, _, vm in pred.propagate_in_video(st, start_frame_idx=6) if w.chk(f"p2/f{t}/video_res_mask", vm) is None]
+        assert p2 == list(range(6, OPTS_FRAMES))
+        assert sorted(st["output_dict_per_obj"][0]["cond_frame_outputs"]) == list(g["cond_frames"])
+        print(f"[parity] predictor options vs reference: max_rel={w.w[0]:.3e} l2={w.w[1]:.3e} pixel disagreement={w.w[2]:.3e}", flush=True)
+    finally:
+        pred.release()
