@@ -18,7 +18,14 @@ The JSON line also carries
                  stream in a second, un-timed pass of the same K steps (sam2mi_profile_enable), vs the 2.5 PFLOP/s dense
                  f16 MFMA peak; every other instantiation and the family totals beside it;
   cpu_baseline - the CPU oracle (oracle/sam2_ref.py, a port of the reference's torch backend) timed on this
-                 box's host cores on the first frames of the same clip (rank 0, N = 1 only).
+                 box's host cores on the first 16 frames of the same clip; value = STEADY-STATE frames/s over frames 8..15
+                 (memory bank full: L = 7), the plan of BASELINE.md 3 (rank 0, N = 1 only);
+  secondary    - (N = 1) fps of the same clip in the f16x3 precision mode (the "masks within 1e-3" class) and images/s of
+                 BASELINE.json configs[4] (16 images x 8 point prompts, one encoder call).
+
+`--backend gloo --stub-predictor` runs the SAME orchestration (rank / world from the environment, process-group init, warm-up,
+barrier, timed steps, MAX-over-ranks reduction, result gather, the JSON line) on the CPU with a stand-in predictor: that is how
+tests/test_dist_gloo.py covers the N > 1 path, which otherwise only ever executes on the driver's 8-GPU node.
 """
 from __future__ import annotations
 
@@ -50,6 +57,129 @@ def _pmc_traffic(kernel):
         return None
 
 
+def _lib_hash():
+    """Hash of the sources libsam2mi.so was built from (sam2_opt_amd/build.py): ties a result to a code state."""
+    try:
+        from sam2_opt_amd.build import built_hash
+        return built_hash()[:16]
+    except Exception:
+        return None
+
+
+def timed_steps(D, dist, device, one_step, warmup: int, steps: int):
+    """The timing contract: W untimed warm-up steps, barrier + device sync, EXACTLY K timed steps, barrier + device sync, MAX of
+    the wall time over ranks, then the trivial gather of (frames, seconds, mask checksum) per rank.
+    `one_step() -> (frames processed, last masks or None)`."""
+    for _ in range(warmup):
+        one_step()
+    D.barrier(dist, device)
+    t0 = time.perf_counter()
+    nframes, last = 0, None
+    for _ in range(steps):
+        n, last = one_step()
+        nframes += n
+    D.barrier(dist, device)
+    dt = time.perf_counter() - t0
+    checksum = float((last > 0).float().mean().item()) if last is not None else 0.0
+    dt, total_frames, records = D.reduce_time_and_gather(dist, nframes, dt, checksum, device)
+    return dt, total_frames, records, nframes, last
+
+
+def stub_main(args, rank, world):
+    """Orchestration-only run on the CPU (gloo): per-rank seeds, process group, barrier, reduction, gather and the JSON line of
+    the real benchmark, with a predictor that just sleeps.  The printed line is marked `"data": "stub"` and is not a result."""
+    from sam2_opt_amd import dist as D
+    device = torch.device("cpu")
+    dist = D.init(args.backend)
+    seed = D.clip_seed_for_rank(2, rank)
+
+    def one_step():
+        time.sleep(0.002 * args.frames * (1 + rank))              # the higher rank is slower: MAX over ranks must pick it
+        return args.frames, torch.full((1, 1, 4, 4), float(seed))
+    dt, total_frames, records, nframes, last = timed_steps(D, dist, device, one_step, args.warmup, args.steps)
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec SAM2.1-hiera-large 1024x1024 video propagation", "value": round(total_frames / dt, 3),
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": args.precision, "data": "stub",
+                          "config": {"workload": "orchestration test (stub predictor on CPU)", "frames_per_step": args.frames,
+                                     "parallelism": f"clips x{world} (one process per rank)", "per_rank": records, "clip_seed_rank0": seed}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def secondary_legs(args, pred, sd, cfg, frames, device):
+    """(a) the same clip in the other precision mode, (b) BASELINE.json configs[4]: 16 images x 8 point prompts."""
+    from sam2_opt_amd.image_predictor import SAM2ImagePredictor
+    from sam2_opt_amd.video_predictor import SAM2VideoPredictor
+    out = {}
+    other = "f16x3" if args.precision == "f16" else "f16"
+    p2 = SAM2VideoPredictor("large", state_dict=sd, encode_batch=args.encode_batch, device=device, overlap_encode=not args.no_overlap, precision=other)
+    try:
+        st = p2.init_state(frames=frames, video_height=1024, video_width=1024)
+        p2.add_new_points_or_box(st, 0, 1, points=np.array([[512.0, 512.0]], np.float32), labels=np.array([1], np.int32))
+        steps = 2
+        for k in range(1 + steps):
+            if k == 1:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            n = sum(1 for _ in p2.propagate_in_video(st))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[f"{other}_frames_per_s"] = round(steps * n / dt, 2)
+        out[f"{other}_note"] = (f"same clip and method, precision={other}, 1 warm-up + {steps} timed steps; "
+                                "f16x3 = split-f16 MFMA operands (3 MFMAs per product), masks within 1e-3 of the reference (measured ~5e-6)")
+    finally:
+        p2.release()
+    B = 16
+    ip = SAM2ImagePredictor("large", state_dict=sd, max_batch=B, device=device, precision=args.precision)
+    try:
+        imgs = [np.random.RandomState(10 + i).randint(0, 256, (1024, 1024, 3)).astype(np.uint8) for i in range(B)]
+        pts = [(np.random.RandomState(100 + i).rand(8, 1, 2) * 1024).astype(np.float32) for i in range(B)]
+        lab = np.ones((8, 1), np.int32)
+        for k in range(3):
+            if k == 1:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            ip.set_image_batch(imgs)
+            for i in range(B):
+                ip._predict(pts[i], lab, None, None, True, True, True, i)
+        torch.cuda.synchronize()
+        out["config5_images_per_s"] = round(2 * B / (time.perf_counter() - t0), 2)
+        out["config5_note"] = (f"BASELINE.json configs[4]: {B} synthetic 1024x1024 uint8 images per set_image_batch (host upload + "
+                               f"normalise included), 8 single-point prompts each, multimask output, precision={args.precision}")
+    finally:
+        ip.release()
+    return out
+
+
+def cpu_baseline_leg(args, sd, cfg, frames):
+    """The CPU oracle (a port of the reference's torch backend; the checker, here only timed) on the first frames of the same clip.
+    Steady state = frames from index 8 on, where the memory bank holds 7 frames."""
+    from oracle import sam2_ref as R
+    ncpu = max(2, min(args.cpu_frames, args.frames))
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
+    cores = torch.get_num_threads()
+    try:
+        vo = R.VideoOracle(sd, cfg, frames[:ncpu].cpu())
+        stamps = []
+        with torch.inference_mode():
+            vo.add_new_points(0, np.array([[512.0, 512.0]], np.float32), np.array([1], np.int32))
+            t1 = time.perf_counter()
+            for _t, _m in vo.propagate(max_frames=ncpu - 1):
+                stamps.append(time.perf_counter())
+        total = stamps[-1] - t1
+        first_steady = 8 if len(stamps) > 9 else 1                       # stamps[i] = end of frame i
+        steady = (len(stamps) - first_steady) / (stamps[-1] - stamps[first_steady - 1])
+        return {"value": round(steady, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+                "sample": f"oracle propagate loop over frames 0..{len(stamps) - 1} of the same clip ({total:.1f} s, fp32 torch CPU kernels, "
+                          f"{cores} threads); value = frames {first_steady}..{len(stamps) - 1} only (memory bank full, L = 7)",
+                "whole_sample_frames_per_s": round(len(stamps) / total, 4)}
+    finally:
+        torch.set_num_threads(old_threads)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,13 +190,22 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="encode and track on one stream (no encoder prefetch stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the clip timed on the CPU oracle")
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the clip timed on the CPU oracle (steady state = frames 8..)")
+    ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads of the baseline leg (reported as `cores`)")
+    ap.add_argument("--precision", default="f16", choices=("f16", "f16x3"), help="precision mode of the timed run")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the f16x3 / config-5 secondary measurements")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
+    ap.add_argument("--stub-predictor", action="store_true", help="CPU stand-in predictor (orchestration tests only; never a result)")
     args = ap.parse_args()
 
     from sam2_opt_amd import dist as D
     rank, local_rank, world = D.rank_world()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.stub_predictor:
+        return stub_main(args, rank, world)
+    if args.backend != "nccl":
+        raise SystemExit("--backend gloo is only for --stub-predictor runs")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     device = torch.device("cuda", local_rank)
@@ -80,7 +219,8 @@ def main():
 
     cfg = get_config("large")
     sd = synthetic_state_dict(cfg, seed=0)
-    pred = SAM2VideoPredictor("large", state_dict=sd, encode_batch=args.encode_batch, device=device, overlap_encode=not args.no_overlap)
+    pred = SAM2VideoPredictor("large", state_dict=sd, encode_batch=args.encode_batch, device=device, overlap_encode=not args.no_overlap,
+                              precision=args.precision)
     frames_u8 = synthetic_frames_u8(seed=D.clip_seed_for_rank(2, rank), num_frames=args.frames)
     frames = normalize_frames(frames_u8, cfg)
     state = pred.init_state(frames=frames, video_height=1024, video_width=1024)       # frames resident in HBM from here on
@@ -100,23 +240,8 @@ def main():
             chk = masks
         return n, chk
 
-    def barrier():
-        D.barrier(dist, device)
-
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    t0 = time.perf_counter()
-    nframes = 0
-    last = None
-    for _ in range(args.steps):
-        n, last = one_step()
-        nframes += n
-    barrier()
-    dt = time.perf_counter() - t0
-    checksum = float((last > 0).float().mean().item())
-    # MAX over ranks + the trivial result gather (frames, seconds, mask checksum) per rank
-    dt, total_frames, records = D.reduce_time_and_gather(dist, nframes, dt, checksum, device)
+    dt, total_frames, records, nframes, last = timed_steps(D, dist, device, one_step, args.warmup, args.steps)
+    checksum = records[rank][2]
     value = total_frames / dt
 
     roofline = None
@@ -172,33 +297,25 @@ def main():
         }
         roofline["whole_path"]["frac_of_mfma_peak"] = round(roofline["whole_path"]["achieved_tflops"] / PEAK_F16_TFLOPS, 4)
 
+    secondary = None
+    if not args.no_secondary and rank == 0 and world == 1:
+        secondary = secondary_legs(args, pred, sd, cfg, frames, device)
+
     cpu_baseline = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
-        from oracle import sam2_ref as R         # the checker, timed as the CPU baseline ("port")
-        ncpu = max(2, min(args.cpu_frames, args.frames))
-        cores = torch.get_num_threads()
-        vo = R.VideoOracle(sd, cfg, frames.cpu())
-        with torch.inference_mode():
-            vo.add_new_points(0, np.array([[512.0, 512.0]], np.float32), np.array([1], np.int32))
-            t1 = time.perf_counter()
-            k = 0
-            for _t, _m in vo.propagate(max_frames=ncpu - 1):
-                k += 1
-            cdt = time.perf_counter() - t1
-        cpu_baseline = {"value": round(k / cdt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-                        "sample": f"propagate loop over the first {k} frames of the same clip (fp32, torch CPU kernels, "
-                                  f"memory bank still growing: L<={k - 1}); {cdt:.1f} s"}
+        cpu_baseline = cpu_baseline_leg(args, sd, cfg, frames)
 
     if rank == 0:
         out = {
             "metric": "frames/sec SAM2.1-hiera-large 1024x1024 video propagation", "value": round(value, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"config3: {args.frames}-frame 1024x1024 clip per GPU, 1 click, 1 object, SAM2.1-hiera-large "
                                    "(random-init weights), propagate_in_video loop", "frames_per_step": args.frames,
                        "encode_batch": args.encode_batch, "overlap_encode_stream": not args.no_overlap, "parallelism": f"clips x{world} (one process per GPU)",
                        "ms_per_frame": round(dt / max(nframes, 1) * 1e3, 3), "mask_checksum": round(checksum, 6), "per_rank": records},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "secondary": secondary,
+            "library": {"source_hash": _lib_hash()},
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -12,7 +12,10 @@
  * torch.cuda.current_stream().cuda_stream); inputs are borrowed for the call, outputs are caller
  * allocated; nothing synchronises the host.  Returns 0 on success, non-zero on error
  * (message: sam2mi_last_error).  No C++ exceptions cross this boundary.
- * A context is not re-entrant: use one context per host thread/stream.
+ * Threading: one context may be driven from several host threads, each on its own stream (the reference's contract,
+ * /root/reference/video_multi_thread.py:36-87).  Entry points serialise their host side per workspace domain and order
+ * consecutive calls that arrive on different streams with an event, so results never depend on the interleaving; calls of
+ * the image-encoder domain and of the tracking domain still overlap.  For full concurrency create one context per thread.
  *
  * Paths below are relative to /root/reference/sam2/sam2/.
  */
@@ -91,6 +94,13 @@ int sam2mi_memory_encoder(sam2mi_ctx* ctx, void* stream, const float* pix_feat, 
  * coords (B,Np,2) px, labels (B,Np) int32 -> sparse (B,Np+1,256), dense (B,256,64,64) [no_mask_embed]. */
 int sam2mi_prompt_encoder(sam2mi_ctx* ctx, void* stream, const float* coords, const int32_t* labels, int B, int Np,
                           float* sparse, float* dense);
+/* The full plug signature inference_prompt(points, boxes, masks) (prompt_encoder.py:215-231).  The caller lays the sparse
+ * prompts out as the reference concatenates them: point coordinates first, then the two corners of each box with labels 2 / 3
+ * (_embed_boxes :168-176 = _embed_points on the corners without padding); `pad` = 1 appends the padding point exactly when the
+ * reference does (boxes is None, :220).  coords (B,Np,2) px, labels (B,Np) -> sparse (B,Np+pad,256); Np may be 0.
+ * masks: (B,1,256,256) mask prompts -> dense = _embed_masks(masks) (:178-181), or NULL -> no_mask_embed. dense (B,256,64,64). */
+int sam2mi_prompt_encoder_ex(sam2mi_ctx* ctx, void* stream, const float* coords, const int32_t* labels, int B, int Np, int pad,
+                             const float* masks, float* sparse, float* dense);
 /* PromptEncoder.get_dense_pe (prompt_encoder.py:113-122) -> (1,256,64,64) */
 int sam2mi_dense_pe(sam2mi_ctx* ctx, void* stream, float* out);
 

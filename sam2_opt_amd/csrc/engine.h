@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -75,8 +76,37 @@ struct ProfAcc {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
 
+// One context may be driven from several host threads, each on its own HIP stream (the reference's contract:
+// /root/reference/video_multi_thread.py:36-87).  The workspaces are shared, so every entry point takes the guard of the
+// workspace domain it uses: the host side of the call is serialised by the mutex, and when the previous call of the domain was
+// enqueued on a DIFFERENT stream the new stream first waits for an event recorded at the end of that call.  Calls that stay
+// on one stream pay one hipEventRecord.  The encoder domain (ws_*) and the tracking domain (t_*, d_*, m_*, p_*) are
+// independent, which is what lets the video predictor run its encoder stream beside the tracking stream.
+struct WsDomain {
+  std::recursive_mutex mu;
+  hipStream_t last = nullptr;
+  hipEvent_t ev = nullptr;
+  bool used = false;
+};
+struct DomainGuard {
+  WsDomain& d;
+  hipStream_t s;
+  DomainGuard(WsDomain& dom, hipStream_t stream) : d(dom), s(stream) {
+    d.mu.lock();
+    if (!d.ev) hipEventCreateWithFlags(&d.ev, hipEventDisableTiming);
+    if (d.used && d.last != s) hipStreamWaitEvent(s, d.ev, 0);
+  }
+  ~DomainGuard() {
+    hipEventRecord(d.ev, s);
+    d.last = s;
+    d.used = true;
+    d.mu.unlock();
+  }
+};
+
 struct sam2mi_ctx {
   sam2mi_config cfg;
+  WsDomain dom_enc, dom_track;
   std::string err;
   bool finalized = false;
   std::unordered_map<std::string, HostW> hw;     // host copies until finalize

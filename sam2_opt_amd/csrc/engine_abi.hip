@@ -20,6 +20,7 @@ static int encode_to_scratch(sam2mi_ctx* ctx, hipStream_t s, const float* img, i
 
 extern "C" int sam2mi_image_encoder(sam2mi_ctx* ctx, void* stream, const float* img, int B, float* const out[7]) {
   REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_enc, S(stream));
   hipStream_t s = S(stream);
   std::vector<EncOut> outs;
   CHKI(encode_to_scratch(ctx, s, img, B, outs));
@@ -61,6 +62,7 @@ __global__ void bilinear_kernel(const float* __restrict__ in, int C, int Hin, in
 
 extern "C" int sam2mi_set_image_e2e(sam2mi_ctx* ctx, void* stream, const float* img01, int B, float* feat0, float* feat1, float* feat2) {
   REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_enc, S(stream));
   hipStream_t s = S(stream);
   const size_t n = (size_t)ctx->cfg.image_size * ctx->cfg.image_size;
   if (B > ctx->cfg.max_batch) return sam2mi_set_error(ctx, __func__, "batch exceeds cfg.max_batch");
@@ -84,6 +86,7 @@ extern "C" int sam2mi_memory_attention(sam2mi_ctx* ctx, void* stream, const floa
                                        const float* memory_pos, const float* memory_exclude, const float* memory_pos_exclude,
                                        int L, int P, int N, float* out) {
   REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_track, S(stream));
   if (N != 1) return sam2mi_set_error(ctx, __func__, "only N == 1 (one object per call) is implemented");
   hipStream_t s = S(stream);
   const int n_rope = L * 4096, Nk = n_rope + P;
@@ -103,6 +106,7 @@ extern "C" int sam2mi_mask_decoder(sam2mi_ctx* ctx, void* stream, const float* s
                                    const float* hr0, const float* hr1, int N, int T, float* masks, float* iou_pred,
                                    float* mask_tokens_out, float* object_score_logits) {
   REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_track, S(stream));
   hipStream_t s = S(stream);
   for (int n0 = 0; n0 < N; n0 += DEC_MAX_N) {
     const int nb = std::min(DEC_MAX_N, N - n0);
@@ -125,6 +129,7 @@ extern "C" int sam2mi_mask_decoder(sam2mi_ctx* ctx, void* stream, const float* s
 // ------------------------------------------------------------------ memory encoder plug
 extern "C" int sam2mi_memory_encoder(sam2mi_ctx* ctx, void* stream, const float* pix_feat, const float* masks, int N, float* x, float* pos) {
   REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_track, S(stream));
   hipStream_t s = S(stream);
   for (int n = 0; n < N; ++n) {
     CHK(transpose_f32_launch(pix_feat + (size_t)n * 256 * 4096, ctx->p_d, 1, 256, 4096, s));
@@ -139,6 +144,7 @@ extern "C" int sam2mi_memory_encoder(sam2mi_ctx* ctx, void* stream, const float*
 extern "C" int sam2mi_prompt_encoder(sam2mi_ctx* ctx, void* stream, const float* coords, const int32_t* labels, int B, int Np,
                                      float* sparse, float* dense) {
   REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_track, S(stream));
   hipStream_t s = S(stream);
   for (int b = 0; b < B; ++b) {
     if (sparse)
@@ -149,6 +155,34 @@ extern "C" int sam2mi_prompt_encoder(sam2mi_ctx* ctx, void* stream, const float*
       CHK(fill_f32_launch(ctx->p_d, 0.f, (size_t)4096 * 256, s));
       CHK(add_rowvec_launch(ctx->p_d, 256, ctx->no_mask_embed, 4096, 256, nullptr, s));
       CHK(transpose_f32_launch(ctx->p_d, dense + (size_t)b * 256 * 4096, 1, 4096, 256, s));
+    }
+  }
+  return 0;
+}
+
+extern "C" int sam2mi_prompt_encoder_ex(sam2mi_ctx* ctx, void* stream, const float* coords, const int32_t* labels, int B, int Np, int pad,
+                                        const float* masks, float* sparse, float* dense) {
+  REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_track, S(stream));
+  hipStream_t s = S(stream);
+  if (B < 1 || Np < 0 || Np + 1 > 64 || (pad != 0 && pad != 1)) return sam2mi_set_error(ctx, __func__, "bad B / Np / pad (Np <= 63)");
+  for (int b = 0; b < B; ++b) {
+    if (sparse && Np + pad > 0) {
+      // the embedding kernel always appends the padding point: build Np + 1 rows in scratch, keep Np + pad of them
+      float* tmp = ctx->d_sparse;
+      CHK(point_embed_launch(Np > 0 ? coords + (size_t)b * Np * 2 : nullptr, Np > 0 ? (const int*)labels + (size_t)b * Np : nullptr, Np, ctx->gauss,
+                             ctx->point_emb4, ctx->not_a_point, (float)ctx->cfg.image_size, tmp, s));
+      CHK(hipMemcpyAsync(sparse + (size_t)b * (Np + pad) * 256, tmp, (size_t)(Np + pad) * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    if (dense) {
+      if (masks) {
+        CHK(mask_embed_launch(masks + (size_t)b * 65536, ctx->mask_embed, ctx->d_dense, s));
+        CHK(transpose_f32_launch(ctx->d_dense, dense + (size_t)b * 256 * 4096, 1, 4096, 256, s));
+      } else {
+        CHK(fill_f32_launch(ctx->p_d, 0.f, (size_t)4096 * 256, s));
+        CHK(add_rowvec_launch(ctx->p_d, 256, ctx->no_mask_embed, 4096, 256, nullptr, s));
+        CHK(transpose_f32_launch(ctx->p_d, dense + (size_t)b * 256 * 4096, 1, 4096, 256, s));
+      }
     }
   }
   return 0;
@@ -200,6 +234,7 @@ extern "C" int sam2mi_resize_bilinear(sam2mi_ctx* ctx, void* stream, const float
 // ============================================================================================ fused video path
 extern "C" int sam2mi_video_encode(sam2mi_ctx* ctx, void* stream, const float* frames, int B, const int32_t* feat_slots) {
   REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_enc, S(stream));
   std::vector<EncOut> outs(B);
   for (int b = 0; b < B; ++b) {
     const int sl = feat_slots[b];
@@ -227,6 +262,7 @@ extern "C" int sam2mi_fill_holes(sam2mi_ctx* ctx, void* stream, const float* mas
 
 extern "C" int sam2mi_video_encode_u8(sam2mi_ctx* ctx, void* stream, const uint8_t* frames_hwc, int B, const int32_t* feat_slots) {
   REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_enc, S(stream));
   if (!frames_hwc) return sam2mi_set_error(ctx, __func__, "null frames");
   std::vector<EncOut> outs(B);
   for (int b = 0; b < B; ++b) {
@@ -309,6 +345,7 @@ static int one_image_in_mask(sam2mi_ctx* ctx, hipStream_t s, const sam2mi_ctx::F
 extern "C" int sam2mi_video_click(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int Np,
                                   const float* mask_logits, int multimask, int bank_slot, const sam2mi_frame_out* out) {
   REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_track, S(stream));
   hipStream_t s = S(stream);
   if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size() || bank_slot < 0 || bank_slot >= (int)ctx->bank.size())
     return sam2mi_set_error(ctx, __func__, "slot out of range");
@@ -329,6 +366,7 @@ extern "C" int sam2mi_video_click(sam2mi_ctx* ctx, void* stream, int feat_slot, 
 // sam2_video_predictor_official.py add_new_mask).  Stores low-res logits, pointer and +-10 score in `bank_slot`.
 extern "C" int sam2mi_video_mask(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* mask1024, int bank_slot, const sam2mi_frame_out* out) {
   REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_track, S(stream));
   hipStream_t s = S(stream);
   if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size() || bank_slot < 0 || bank_slot >= (int)ctx->bank.size())
     return sam2mi_set_error(ctx, __func__, "slot out of range");
@@ -367,6 +405,7 @@ extern "C" int sam2mi_video_mask(sam2mi_ctx* ctx, void* stream, int feat_slot, c
 extern "C" int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int N, int Np,
                                     int multimask, float* masks_out, float* iou_out) {
   REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_track, S(stream));
   hipStream_t s = S(stream);
   if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size()) return sam2mi_set_error(ctx, __func__, "slot out of range");
   if (N < 1) return sam2mi_set_error(ctx, __func__, "no prompts");
@@ -400,6 +439,7 @@ extern "C" int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot
 
 extern "C" int sam2mi_video_encode_memory(sam2mi_ctx* ctx, void* stream, int feat_slot, int bank_slot, int is_mask_from_pts) {
   REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_track, S(stream));
   hipStream_t s = S(stream);
   if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size() || bank_slot < 0 || bank_slot >= (int)ctx->bank.size())
     return sam2mi_set_error(ctx, __func__, "slot out of range");
@@ -456,6 +496,7 @@ static int assemble_object_memory(sam2mi_ctx* ctx, hipStream_t s, const sam2mi_m
 extern "C" int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, const sam2mi_mem_select* sel, const sam2mi_prompt* prompt,
                                   int bank_slot, int run_mem_encoder, const sam2mi_frame_out* out) {
   REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_track, S(stream));
   hipStream_t s = S(stream);
   if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size() || bank_slot < 0 || bank_slot >= (int)ctx->bank.size())
     return sam2mi_set_error(ctx, __func__, "slot out of range");
@@ -488,6 +529,7 @@ extern "C" int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, 
 extern "C" int sam2mi_video_track_batch(sam2mi_ctx* ctx, void* stream, int feat_slot, int N, const sam2mi_mem_select* sels,
                                         const int32_t* bank_slots, int run_mem_encoder, const sam2mi_frame_out* outs) {
   REQUIRE_READY();
+  DomainGuard guard_(ctx->dom_track, S(stream));
   hipStream_t s = S(stream);
   if (N < 1 || N > TRACK_MAX_N) return sam2mi_set_error(ctx, __func__, "object batch out of range (1..8)");
   if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size()) return sam2mi_set_error(ctx, __func__, "slot out of range");

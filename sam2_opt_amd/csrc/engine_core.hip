@@ -343,6 +343,8 @@ extern "C" void sam2mi_destroy(sam2mi_ctx* ctx) {
   if (!ctx) return;
   hipDeviceSynchronize();
   for (void* p : ctx->allocs) hipFree(p);
+  for (WsDomain* d : {&ctx->dom_enc, &ctx->dom_track})
+    if (d->ev) hipEventDestroy(d->ev);
   for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp, &ctx->prof_xs, &ctx->prof_ks}) {
     for (auto& pr : a->pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto& pr : a->pending) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libsam2mi.so")
 EXPORTS = [
     "sam2mi_abi_version", "sam2mi_create", "sam2mi_destroy", "sam2mi_last_error", "sam2mi_load_weight",
     "sam2mi_finalize_weights", "sam2mi_image_encoder", "sam2mi_set_image_e2e", "sam2mi_memory_attention",
-    "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_dense_pe", "sam2mi_video_encode", "sam2mi_video_encode_u8", "sam2mi_fill_holes", "sam2mi_set_fill_hole_area",
+    "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_prompt_encoder_ex", "sam2mi_dense_pe", "sam2mi_video_encode", "sam2mi_video_encode_u8", "sam2mi_fill_holes", "sam2mi_set_fill_hole_area",
     "sam2mi_video_click", "sam2mi_video_mask", "sam2mi_image_predict", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_video_track_batch", "sam2mi_resize_bilinear",
     "sam2mi_stream_create_reserved", "sam2mi_stream_destroy", "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_profile_read_mlp", "sam2mi_profile_read_xs", "sam2mi_profile_read_ks", "sam2mi_profile_read_kernels", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
     "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench", "sam2mi_debug_mlp",
@@ -209,6 +209,31 @@ class Engine:
         sparse, dense = self.new(B, Np + 1, 256), self.new(B, 256, 64, 64)
         self._check(self.lib.sam2mi_prompt_encoder(self.h, self.stream, _ptr(coords), _ptr(labels), B, Np, _ptr(sparse), _ptr(dense)),
                     "sam2mi_prompt_encoder")
+        return sparse, dense
+
+    def prompt_encoder_full(self, points=None, boxes=None, masks=None):
+        """PromptEncoder.inference_prompt(points, boxes, masks) (prompt_encoder.py:215-231): points = (coords (B,Np,2), labels
+        (B,Np)) or None, boxes (B,4) or None, masks (B,1,256,256) or None -> (sparse (B,S,256), dense (B,256,64,64))."""
+        coords = labels = None
+        if points is not None:
+            coords, labels = points[0].to(self.device, torch.float32), points[1].to(self.device, torch.int32)
+        if boxes is not None:                    # the two corners of a box are points with labels 2 and 3 (_embed_boxes :168-176)
+            bc = boxes.to(self.device, torch.float32).reshape(-1, 2, 2)
+            bl = torch.tensor([2, 3], dtype=torch.int32, device=self.device).expand(bc.shape[0], 2)
+            coords = bc if coords is None else torch.cat([coords, bc], dim=1)
+            labels = bl if labels is None else torch.cat([labels, bl], dim=1)
+        B = coords.shape[0] if coords is not None else (masks.shape[0] if masks is not None else 1)
+        Np = 0 if coords is None else coords.shape[1]
+        pad = 1 if (points is not None and boxes is None) else 0
+        if coords is not None:
+            coords, labels = coords.contiguous(), labels.contiguous()
+        if masks is not None:
+            masks = masks.to(self.device, torch.float32).contiguous()
+            if tuple(masks.shape[1:]) != (1, 256, 256) or masks.shape[0] != B:
+                raise ValueError("mask prompts must be (B,1,256,256)")
+        sparse, dense = self.new(B, Np + pad, 256), self.new(B, 256, 64, 64)
+        self._check(self.lib.sam2mi_prompt_encoder_ex(self.h, self.stream, _ptr(coords), _ptr(labels), B, Np, pad, _ptr(masks), _ptr(sparse),
+                                                      _ptr(dense)), "sam2mi_prompt_encoder_ex")
         return sparse, dense
 
     def dense_pe(self):

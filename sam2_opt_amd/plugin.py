@@ -45,22 +45,47 @@ class HipExecutor:
         pass                                   # the engine is shared; released by release_hip()
 
 
-def _engine_for(model) -> Engine:
+def _check_hiera_large(sd):
+    """The HIP path implements the hiera-large trunk (window spec 8/4/16/8, no window padding).  Anything else must fail here,
+    at attach time, not as out-of-bounds device reads."""
+    from .config import get_config
+    cfg = get_config("large")
+    w = sd.get("image_encoder.trunk.patch_embed.proj.weight")
+    nblk = len({k.split(".")[3] for k in sd if k.startswith("image_encoder.trunk.blocks.")})
+    if w is None or w.shape[0] != cfg["embed_dim"] or nblk != sum(cfg["stages"]):
+        got = None if w is None else int(w.shape[0])
+        raise RuntimeError(f"speedup('hip') supports SAM 2.1 hiera-large only (embed_dim {cfg['embed_dim']}, {sum(cfg['stages'])} blocks); "
+                           f"this model has embed_dim {got}, {nblk} blocks")
+
+
+def _engine_for(model, precision: str = "f16", engine=None) -> Engine:
     eng = getattr(model, "_sam2mi_engine", None)
     if eng is None:
-        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-        dev = next(model.parameters()).device
-        if dev.type != "cuda":
-            raise RuntimeError("speedup('hip') needs the model on a ROCm GPU (model.to('cuda'))")
-        eng = Engine("large", state_dict=sd, max_batch=1, device=dev)
+        if engine is not None:                   # injected (tests drive the adapter without a GPU)
+            eng = engine
+        else:
+            sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+            _check_hiera_large(sd)
+            dev = next(model.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("speedup('hip') needs the model on a ROCm GPU (model.to('cuda'))")
+            eng = Engine("large", state_dict=sd, max_batch=1, device=dev, precision=precision)
         model._sam2mi_engine = eng
     return eng
 
 
-def speedup_hip(predictor, plugs=("image", "memory_attention", "mask_decoder", "memory_encoder")):
-    """Install the HIP backend on a reference SAM2VideoPredictor / SAM2Base / SAM2ImagePredictor."""
+PLUGS = ("image", "memory_attention", "mask_decoder", "memory_encoder", "prompt_encoder")
+
+
+def speedup_hip(predictor, plugs=PLUGS, precision: str = "f16", engine=None):
+    """Install the HIP backend on a reference SAM2VideoPredictor / SAM2Base / SAM2ImagePredictor: re-points exactly the
+    attributes the reference's own `set_runtime_backend` methods re-point and keeps executor objects in
+    `backend_contexts`, so `predictor.speedup("torch")` / `release()` restore the PyTorch path as for any other backend."""
     model = getattr(predictor, "model", predictor)        # SAM2ImagePredictor wraps the SAM2Base in .model
-    eng = _engine_for(model)
+    unknown = set(plugs) - set(PLUGS)
+    if unknown:
+        raise ValueError(f"unknown plug(s) {sorted(unknown)}; choose from {PLUGS}")
+    eng = _engine_for(model, precision, engine)
     if "image" in plugs:
         ex = HipExecutor(eng, eng.image_encoder, 1)
         model.backend_contexts = [ex]
@@ -86,6 +111,14 @@ def speedup_hip(predictor, plugs=("image", "memory_attention", "mask_decoder", "
         ex = HipExecutor(eng, eng.memory_encoder, 2)
         me.backend_contexts = [ex]
         me.inference_memory = lambda pix, m, _ex=ex: tuple(_ex.Inference([pix, m]))
+    pe = getattr(model, "sam_prompt_encoder", None)
+    if pe is not None and "prompt_encoder" in plugs:
+        # PromptEncoder.inference_prompt(points, boxes, masks) (prompt_encoder.py:211,:215-231): arguments are optional /
+        # a tuple, so this plug does not go through the list-of-tensors executor call; the executor object is still kept in
+        # backend_contexts for Release()
+        ex = HipExecutor(eng, eng.prompt_encoder_full, 3)
+        pe.backend_contexts = [ex]
+        pe.inference_prompt = lambda points, boxes, masks, _e=eng: _e.prompt_encoder_full(points, boxes, masks)
     return predictor
 
 
@@ -94,13 +127,12 @@ def release_hip(predictor):
     model = getattr(predictor, "model", predictor)
     seen = set()
     for mod in (predictor, model, getattr(model, "memory_attention", None), getattr(model, "sam_mask_decoder", None),
-                getattr(model, "memory_encoder", None)):
+                getattr(model, "memory_encoder", None), getattr(model, "sam_prompt_encoder", None)):
         if mod is None or id(mod) in seen:
             continue
         seen.add(id(mod))
         if hasattr(mod, "set_runtime_backend"):
-            mod.backend_contexts = []
-            mod.set_runtime_backend("torch")
+            mod.set_runtime_backend("torch")        # releases the executors in backend_contexts, then re-points the attributes
     eng = getattr(model, "_sam2mi_engine", None)
     if eng is not None:
         eng.close()

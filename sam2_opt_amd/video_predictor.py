@@ -18,6 +18,8 @@ Differences from the reference, all deliberate:
 """
 from __future__ import annotations
 
+import functools
+import threading
 from collections import OrderedDict
 from typing import Optional
 
@@ -28,6 +30,16 @@ from .config import get_config
 from .memory_select import select_memory
 from .native import Engine, MemSelect
 from .synthetic import normalize_frames
+
+
+def _locked(fn):
+    """Serialise the host side of a predictor call: one predictor may be driven from several threads, each under its own
+    torch.cuda.Stream and with its own inference state (/root/reference/video_multi_thread.py:36-87)."""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        with self._lock:
+            return fn(self, *a, **k)
+    return wrapper
 
 
 class SAM2VideoPredictor:
@@ -81,6 +93,7 @@ class SAM2VideoPredictor:
         # frame features are recomputable, so the feature cache is ONE least-recently-encoded list over all live states:
         # (id(state), frame) -> state; a state that needs slots evicts the oldest entry, whichever state it belongs to
         self._feat_lru = OrderedDict()
+        self._lock = threading.RLock()
 
     # ------------------------------------------------------------------ backend switch (reference: speedup :45-145)
     def speedup(self, backend: str = "hip", use_cache: bool = True, model_root_path=None):
@@ -94,6 +107,7 @@ class SAM2VideoPredictor:
 
     # ------------------------------------------------------------------ state
     @torch.inference_mode()
+    @_locked
     def init_state(self, video_path=None, frames: Optional[torch.Tensor] = None, video_height: Optional[int] = None,
                    video_width: Optional[int] = None, offload_video_to_cpu: bool = False, frames_u8=None, **_unused):
         """`frames`: float32 (T,3,1024,1024) already /255 and mean/std normalised (what load_video_frames returns),
@@ -117,6 +131,7 @@ class SAM2VideoPredictor:
             "feat_slot_of_frame": OrderedDict(),
             "feat_events": {},          # frame -> event recorded on the encoder stream (features still in flight)
             "bank_slots_held": set(),   # memory-bank slots borrowed from the predictor
+            "stream": torch.cuda.current_stream(self.device),       # the stream this state is driven on (updated by every call)
             "stale_outputs": OrderedDict(),   # id(out) -> non-cond output no later frame attends to: recycled when the bank is full
         }
         self._sync_encoder_stream()
@@ -129,6 +144,7 @@ class SAM2VideoPredictor:
         if self._enc_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._enc_stream)
 
+    @_locked
     def reset_state(self, st):
         self._sync_encoder_stream()
         for d in list(st["output_dict_per_obj"].values()) + list(st["temp_output_dict_per_obj"].values()):
@@ -142,6 +158,7 @@ class SAM2VideoPredictor:
             st[k].clear()
         st["obj_ids"] = []
 
+    @_locked
     def release_state(self, st):
         """Return every slot the state borrowed (feature cache too); the state must not be used afterwards."""
         self.reset_state(st)
@@ -199,7 +216,7 @@ class SAM2VideoPredictor:
             self._free_bank_slots.append(out["slot"])
             out["slot"] = None
 
-    def _encode_batch(self, st, start: int, forward: bool, side: bool):
+    def _encode_batch(self, st, start: int, forward: bool, side: bool, keep=None):
         """Encode up to `encode_batch` uncached frames from `start` in the tracking direction into feature-cache slots."""
         m = st["feat_slot_of_frame"]
         T = st["num_frames"]
@@ -207,10 +224,17 @@ class SAM2VideoPredictor:
         idxs = [t for t in range(start, start + step * self.encode_batch, step) if 0 <= t < T and t not in m]
         if not idxs:
             return
-        while len(self._free_feat_slots) < len(idxs):          # evict the oldest cached frames (of any state)
-            (_, t_old), st_old = self._feat_lru.popitem(last=False)
+        main = torch.cuda.current_stream(self.device)
+        st["stream"] = main
+        foreign = set()                                         # streams of OTHER states whose cached frames get evicted
+        while len(self._free_feat_slots) < len(idxs):          # evict the least recently used cached frames (of any state)
+            key_old = next(k for k in self._feat_lru if k != (id(st), keep))       # never the frame the caller is about to use
+            st_old = self._feat_lru.pop(key_old)
+            t_old = key_old[1]
             self._free_feat_slots.append(st_old["feat_slot_of_frame"].pop(t_old))
             st_old["feat_events"].pop(t_old, None)
+            if st_old is not st and st_old["stream"] != main:
+                foreign.add(st_old["stream"])
         slots = [self._free_feat_slots.pop() for _ in idxs]
 
         def run():
@@ -220,8 +244,9 @@ class SAM2VideoPredictor:
             else:
                 self.engine.video_encode(imgs.to(self.device, dtype=torch.float32).contiguous(), slots)
         if side:
-            main = torch.cuda.current_stream(self.device)
             self._enc_stream.wait_stream(main)                   # the evicted slots were read by work already queued on `main`
+            for so in foreign:                                   # ... or on the stream of the state they were taken from
+                self._enc_stream.wait_stream(so)
             with torch.cuda.stream(self._enc_stream):
                 run()
                 ev = torch.cuda.Event()
@@ -230,6 +255,8 @@ class SAM2VideoPredictor:
                 st["feat_events"][t] = ev
         else:
             self._sync_encoder_stream()          # a prefetch in flight uses the same encoder workspace
+            for so in foreign:
+                main.wait_stream(so)
             run()
         for t, sl in zip(idxs, slots):
             m[t] = sl
@@ -242,6 +269,7 @@ class SAM2VideoPredictor:
         m = st["feat_slot_of_frame"]
         if frame_idx not in m:
             self._encode_batch(st, frame_idx, forward, side=False)
+        self._feat_lru.move_to_end((id(st), frame_idx))          # most recently used
         ev = st["feat_events"].pop(frame_idx, None)
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
@@ -251,11 +279,12 @@ class SAM2VideoPredictor:
             while t in m and abs(t - frame_idx) <= self.encode_batch:
                 t += step
             if 0 <= t < st["num_frames"] and abs(t - frame_idx) <= self.encode_batch:
-                self._encode_batch(st, t, forward, side=True)
+                self._encode_batch(st, t, forward, side=True, keep=frame_idx)
         return m[frame_idx]
 
     # ------------------------------------------------------------------ prompts
     @torch.inference_mode()
+    @_locked
     def add_new_points_or_box(self, inference_state, frame_idx, obj_id, points=None, labels=None, clear_old_points=True,
                               normalize_coords=True, box=None):
         st = inference_state
@@ -312,6 +341,7 @@ class SAM2VideoPredictor:
         return self.add_new_points_or_box(*a, **k)
 
     @torch.inference_mode()
+    @_locked
     def add_new_mask(self, inference_state, frame_idx, obj_id, mask):
         """Mask prompt (sam2_video_predictor_official.py:403-489): the mask becomes the frame's output as it is
         (SAM2Base._use_mask_as_output); the SAM decoder only supplies the object pointer."""
@@ -340,6 +370,7 @@ class SAM2VideoPredictor:
         return frame_idx, st["obj_ids"], self._video_res(st, self._consolidated(st, frame_idx))
 
     @torch.inference_mode()
+    @_locked
     def clear_all_prompts_in_frame(self, inference_state, frame_idx, obj_id, need_output=True):
         """Remove all input points / mask of an object on a frame (sam2_video_predictor_official.py:739-779): the frame's
         conditioning output, if any, is downgraded to a non-conditioning one."""
@@ -360,6 +391,7 @@ class SAM2VideoPredictor:
         return frame_idx, st["obj_ids"], self._video_res(st, self._consolidated(st, frame_idx))
 
     @torch.inference_mode()
+    @_locked
     def remove_object(self, inference_state, obj_id, strict=False, need_output=True):
         """Remove an object id from the tracking state (sam2_video_predictor_official.py:973-1060)."""
         st = inference_state
@@ -418,6 +450,7 @@ class SAM2VideoPredictor:
 
     # ------------------------------------------------------------------ propagation
     @torch.inference_mode()
+    @_locked
     def propagate_in_video_preflight(self, inference_state):
         st = inference_state
         if len(st["obj_ids"]) == 0:
@@ -510,48 +543,51 @@ class SAM2VideoPredictor:
             end = min(start_frame_idx + max_frame_num_to_track, num_frames - 1)
             order = range(start_frame_idx, end + 1)
         for frame_idx in order:
-            per_obj = [None] * len(st["obj_ids"])
-            todo = []                                          # objects to track on this frame (no stored conditioning output)
-            for obj_idx in range(len(st["obj_ids"])):
-                od = st["output_dict_per_obj"][obj_idx]
-                if frame_idx in od["cond_frame_outputs"]:
-                    per_obj[obj_idx] = od["cond_frame_outputs"][frame_idx]["pred_masks"]
-                    if self.clear_non_cond_mem_around_input:
-                        self._clear_obj_non_cond_mem_around_input(st, frame_idx, obj_idx)
-                else:
-                    todo.append(obj_idx)
-            if todo:
-                feat = self._ensure_features(st, frame_idx, forward=not reverse)
-            # the reference loops objects with B = 1 (:691-725); here up to 8 objects go through one batched pass
-            for c0 in range(0, len(todo), self.object_batch):
-                chunk = todo[c0:c0 + self.object_batch]
-                sels, slots, outs_l = [], [], []
-                for obj_idx in chunk:
+            with self._lock:                                   # host side of one frame; never held across the yield
+                st["stream"] = torch.cuda.current_stream(self.device)
+                per_obj = [None] * len(st["obj_ids"])
+                todo = []                                          # objects to track on this frame (no stored conditioning output)
+                for obj_idx in range(len(st["obj_ids"])):
                     od = st["output_dict_per_obj"][obj_idx]
-                    sels.append(self._select_memory(od, frame_idx, num_frames, reverse))
-                    self._free_bank(st, od["non_cond_frame_outputs"].pop(frame_idx, None))
-                    slots.append(self._alloc_bank(st, protect={sl for s_ in sels for sl in _sel_slots(s_)}))
-                    outs = dict(low_res_masks=self.engine.new(1, 1, 256, 256), object_score_logits=self.engine.new(1, 1))
-                    if self.debug_trace is not None:
-                        outs.update(pix_feat=self.engine.new(4096, 1, 256), ious=self.engine.new(1, 3), obj_ptr=self.engine.new(1, 256),
-                                    low_res_multimasks=self.engine.new(1, 3, 256, 256),
-                                    best_idx=self.engine.new(1, dtype=torch.int32))
-                        self.debug_trace[(obj_idx, frame_idx)] = dict(outs, L=sels[-1].num_mem, P=4 * sels[-1].num_ptr)
-                    outs_l.append(outs)
-                if len(chunk) == 1:
-                    self.engine.video_track(feat, sels[0], slots[0], True, outs_l[0])
-                else:
-                    self.engine.video_track_batch(feat, sels, slots, True, outs_l)
-                for obj_idx, slot, outs in zip(chunk, slots, outs_l):
-                    od = st["output_dict_per_obj"][obj_idx]
-                    od["non_cond_frame_outputs"][frame_idx] = dict(slot=slot, pred_masks=outs["low_res_masks"],
-                                                                   object_score_logits=outs["object_score_logits"], has_mem=True, is_pts=False)
-                    self._release_stale(st, obj_idx, od, frame_idx, reverse)
-                    per_obj[obj_idx] = outs["low_res_masks"]
-            for obj_idx in range(len(st["obj_ids"])):
-                st["frames_tracked_per_obj"][obj_idx][frame_idx] = {"reverse": reverse}
-            low_all = torch.cat(per_obj, dim=0) if len(per_obj) > 1 else per_obj[0]
-            yield frame_idx, st["obj_ids"], self._video_res(st, low_all)
+                    if frame_idx in od["cond_frame_outputs"]:
+                        per_obj[obj_idx] = od["cond_frame_outputs"][frame_idx]["pred_masks"]
+                        if self.clear_non_cond_mem_around_input:
+                            self._clear_obj_non_cond_mem_around_input(st, frame_idx, obj_idx)
+                    else:
+                        todo.append(obj_idx)
+                if todo:
+                    feat = self._ensure_features(st, frame_idx, forward=not reverse)
+                # the reference loops objects with B = 1 (:691-725); here up to 8 objects go through one batched pass
+                for c0 in range(0, len(todo), self.object_batch):
+                    chunk = todo[c0:c0 + self.object_batch]
+                    sels, slots, outs_l = [], [], []
+                    for obj_idx in chunk:
+                        od = st["output_dict_per_obj"][obj_idx]
+                        sels.append(self._select_memory(od, frame_idx, num_frames, reverse))
+                        self._free_bank(st, od["non_cond_frame_outputs"].pop(frame_idx, None))
+                        slots.append(self._alloc_bank(st, protect={sl for s_ in sels for sl in _sel_slots(s_)}))
+                        outs = dict(low_res_masks=self.engine.new(1, 1, 256, 256), object_score_logits=self.engine.new(1, 1))
+                        if self.debug_trace is not None:
+                            outs.update(pix_feat=self.engine.new(4096, 1, 256), ious=self.engine.new(1, 3), obj_ptr=self.engine.new(1, 256),
+                                        low_res_multimasks=self.engine.new(1, 3, 256, 256),
+                                        best_idx=self.engine.new(1, dtype=torch.int32))
+                            self.debug_trace[(obj_idx, frame_idx)] = dict(outs, L=sels[-1].num_mem, P=4 * sels[-1].num_ptr)
+                        outs_l.append(outs)
+                    if len(chunk) == 1:
+                        self.engine.video_track(feat, sels[0], slots[0], True, outs_l[0])
+                    else:
+                        self.engine.video_track_batch(feat, sels, slots, True, outs_l)
+                    for obj_idx, slot, outs in zip(chunk, slots, outs_l):
+                        od = st["output_dict_per_obj"][obj_idx]
+                        od["non_cond_frame_outputs"][frame_idx] = dict(slot=slot, pred_masks=outs["low_res_masks"],
+                                                                       object_score_logits=outs["object_score_logits"], has_mem=True, is_pts=False)
+                        self._release_stale(st, obj_idx, od, frame_idx, reverse)
+                        per_obj[obj_idx] = outs["low_res_masks"]
+                for obj_idx in range(len(st["obj_ids"])):
+                    st["frames_tracked_per_obj"][obj_idx][frame_idx] = {"reverse": reverse}
+                low_all = torch.cat(per_obj, dim=0) if len(per_obj) > 1 else per_obj[0]
+                result = (frame_idx, st["obj_ids"], self._video_res(st, low_all))
+            yield result
 
 
 def _sel_slots(sel: MemSelect):

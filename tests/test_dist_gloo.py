@@ -52,3 +52,41 @@ def test_single_process_passthrough():
     os.environ.pop("WORLD_SIZE", None)
     assert D.init("gloo") is None
     assert D.reduce_time_and_gather(None, 100, 0.5, 0.1, torch.device("cpu")) == (0.5, 100, [(100, 0.5, 0.1)])
+
+
+def test_bench_orchestration_two_ranks_gloo():
+    """bench.py's own N > 1 code path - launched exactly as the driver launches it (torch.distributed.run, one process per
+    rank, RANK / WORLD_SIZE / MASTER_* from the environment) - with the gloo backend and a stand-in predictor: process-group
+    init, W warm-up + K timed steps between barriers, MAX-over-ranks time, the per-rank gather and the single JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--frames", "10", "--backend", "gloo", "--stub-predictor"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                        # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak" and out["data"] == "stub"
+    recs = out["config"]["per_rank"]
+    assert [r_[0] for r_ in recs] == [30, 30]                               # K * frames per rank
+    slow = max(r_[1] for r_ in recs)
+    assert abs(out["ms_per_step"] * 3 / 1e3 - slow) < 0.05                  # the time is the MAX over ranks ...
+    assert abs(out["value"] - 60 / slow) / out["value"] < 0.05              # ... and the value the whole-job aggregate over it
+    # the timed region ends with a barrier, so BOTH ranks measure the pace of the slow one (rank 1 sleeps 2 x 20 ms per step)
+    assert min(r_[1] for r_ in recs) >= 3 * 0.04 * 0.95
+    assert out["config"]["clip_seed_rank0"] == 2 and recs[0][2] == recs[1][2] == 1.0
+
+
+def test_bench_refuses_mismatched_world():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-predictor", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=120, env=env, cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

@@ -64,3 +64,45 @@ def test_batched_prompts_equal_single_prompt_calls(sd_large):
         assert torch.equal(m2[0], m1[17]) and torch.equal(s2[0], s1[17])
     finally:
         pred.release()
+
+
+def test_config5_batch16_eight_prompts_each(sd_large, cfg_large):
+    """BASELINE.json configs[4] at its stated size: ONE encoder call on 16 images (M = 65,536 tokens in stage 3: the kernel
+    selection differs from small batches), 8 independent single-point prompts per image.  Images 3 and 12 are held to the
+    CPU oracle, all 16 to the batch-1 HIP result (the batch-1 path is the one the oracle tests above pin)."""
+    import time
+    from oracle import sam2_ref as R
+    from sam2_opt_amd.image_predictor import SAM2ImagePredictor
+    B = 16
+    imgs = [np.random.RandomState(10 + i).randint(0, 256, (1024, 1024, 3)).astype(np.uint8) for i in range(B)]
+    pts = [(np.random.RandomState(100 + i).rand(8, 1, 2) * 1024).astype(np.float32) for i in range(B)]
+    lab = np.ones((8, 1), np.int32)
+    p16 = SAM2ImagePredictor("large", state_dict=sd_large, max_batch=B)
+    p1 = SAM2ImagePredictor("large", state_dict=sd_large, max_batch=1)
+    try:
+        p16.set_image_batch(imgs)                                  # warm-up, then a timed pass for the images/s figure
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        p16.set_image_batch(imgs)
+        got = [p16._predict(pts[i], lab, None, None, True, True, True, i) for i in range(B)]
+        torch.cuda.synchronize()
+        print(f"[config5] 16 images x 8 prompts: {B / (time.perf_counter() - t0):.1f} images/s (one encoder call of 16)", flush=True)
+        for i in range(B):
+            p1.set_image(imgs[i])
+            m1, s1, l1 = p1._predict(pts[i], lab, None, None, True, True, True, 0)
+            m, s, l = got[i]
+            assert m.shape == (8, 3, 1024, 1024) and s.shape == (8, 3)
+            check(f"config5 image {i} masks: batch-16 vs batch-1", m, m1, 4e-3, 2e-3)
+            check(f"config5 image {i} ious: batch-16 vs batch-1", s, s1, 2e-3, 2e-3)
+        for i in (3, 12):
+            img01 = torch.from_numpy(imgs[i]).permute(2, 0, 1)[None].float() / 255.0
+            with torch.inference_mode():
+                feats = R.set_image_e2e(img01, sd_large, cfg_large)
+                rm, ri, rl = R.image_predict(feats, torch.from_numpy(pts[i]), torch.from_numpy(lab), True, (1024, 1024), sd_large, cfg_large)
+            m, s, l = got[i]
+            check(f"config5 image {i} masks vs oracle", m, rm, 1e-2, 5e-3)
+            check(f"config5 image {i} ious vs oracle", s, ri, 5e-3, 5e-3)
+            check(f"config5 image {i} low_res vs oracle", l, rl, 1e-2, 5e-3)
+    finally:
+        p16.release()
+        p1.release()

@@ -25,7 +25,7 @@ class _FakeSam2Base(_Sub):
     def __init__(self, sd, device):
         super().__init__()
         self._sd = {k: v.to(device) for k, v in sd.items()}
-        self.memory_attention, self.sam_mask_decoder, self.memory_encoder = _Sub(), _Sub(), _Sub()
+        self.memory_attention, self.sam_mask_decoder, self.memory_encoder, self.sam_prompt_encoder = _Sub(), _Sub(), _Sub(), _Sub()
 
     def state_dict(self):
         return self._sd
@@ -60,6 +60,12 @@ def test_speedup_hip_installs_reference_plugs(sd_large, cfg_large):
         check("plugin memenc", x, rx, 5e-3, 2e-3)
         outs = model.inference_image(randn(3, 1, 3, 1024, 1024).to(dev))
         assert len(outs) == 7 and tuple(outs[4].shape) == (1, 32, 256, 256)
+        pts, lab = plug_inputs(cfg_large)["prompt"]
+        sp, de = model.sam_prompt_encoder.inference_prompt((pts.to(dev), lab.to(dev)), None, None)
+        with torch.inference_mode():
+            rsp, rde = R.prompt_encoder(pts, lab, sd_large, cfg_large)
+        check("plugin prompt/sparse", sp, rsp, 1e-4, 1e-4)
+        check("plugin prompt/dense", de, rde.contiguous(), 1e-6, 1e-6)
     finally:
         release_hip(model)
-    assert model.memory_attention.restored == 1 and model.restored == 1
+    assert model.memory_attention.restored == 1 and model.restored == 1 and model.sam_prompt_encoder.restored == 1

@@ -151,3 +151,30 @@ def test_prompt_encoder(eng, sd_large, cfg_large):
     check("prompt/sparse", gs, sp, 1e-4, 1e-4)
     check("prompt/dense", gd, de.contiguous(), 1e-6, 1e-6)
     check("prompt/dense_pe", eng.dense_pe(), dpe, 1e-4, 1e-4)
+
+
+def test_prompt_encoder_points_boxes_masks(eng):
+    """The full plug signature inference_prompt(points, boxes, masks) (prompt_encoder.py:215-231) vs the REAL reference
+    (tests/golden/large_box4.npz, oracle/gen_golden.py::gen_box): points + boxes (no padding point, corners with labels 2 / 3),
+    boxes alone, points + a mask prompt (dense = _embed_masks)."""
+    import os
+    from sam2_opt_amd.synthetic import randn
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_box4.npz"))
+
+    def chk(name, t, tol):
+        stride, size = (int(v) for v in g[name + "/meta"])
+        a = t.detach().float().cpu().numpy().reshape(-1)
+        assert a.size == size and list(t.shape) == list(g[name + "/shape"]), (name, t.shape)
+        got, ref = a[::stride], g[name + "/sample"]
+        m = float(np.abs(got - ref).max() / np.abs(ref).max())
+        print(f"[parity] {name}: max_rel={m:.3e}", flush=True)
+        assert m <= tol, (name, m)
+    pts = (torch.tensor([[[100.0, 200.0], [512.0, 512.0]], [[7.5, 900.0], [640.0, 32.0]]]).cuda(), torch.tensor([[1, 0], [1, 1]], dtype=torch.int32).cuda())
+    boxes = torch.tensor([[10.0, 20.0, 300.0, 400.0], [512.0, 512.0, 1000.0, 900.0]]).cuda()
+    sp, de = eng.prompt_encoder_full(pts, boxes, None)
+    chk("plug/points_boxes/sparse", sp, 1e-4)
+    sp, _ = eng.prompt_encoder_full(None, boxes, None)
+    chk("plug/boxes/sparse", sp, 1e-4)
+    sp, de = eng.prompt_encoder_full(pts, None, randn(77, 2, 1, 256, 256, scale=3.0).cuda())
+    chk("plug/points_mask/sparse", sp, 1e-4)
+    chk("plug/points_mask/dense", de, 1e-4)
