@@ -76,6 +76,39 @@ static __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// LayerNorm fused into an MFMA operand load.  A token row of K = 16 KS channels is spread over the two lane halves of a
+// wave in fragment order (lane (fr, fh) holds channels 16 s + 8 fh + e): `xp` = row base + 8 fh.  The row is read twice (the
+// second read comes from cache): once for the f32 sum / sum of squares, once to normalise into f16 fragments.  The affine
+// part is NOT applied here - the packer folds it into the consumer:  W (g * xhat + b) + c = (W diag g) xhat + (W b + c).
+template <int KS>
+static __device__ __forceinline__ void ln_row_fragments(const float* __restrict__ xp, float eps, half8 (&xf)[KS]) {
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(xp + 16 * s), b = *reinterpret_cast<const f32x4*>(xp + 16 * s + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s1 += a[e] + b[e];
+      s2 = fmaf(a[e], a[e], fmaf(b[e], b[e], s2));
+    }
+  }
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  const float mean = s1 * (1.0f / (16 * KS));
+  const float rstd = rsqrtf(fmaxf(s2 * (1.0f / (16 * KS)) - mean * mean, 0.f) + eps);
+  const float shift = -mean * rstd;
+  asm volatile("" ::: "memory");                 // the second pass RE-READS the row (288 live f32 registers would not fit)
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(xp + 16 * s), b = *reinterpret_cast<const f32x4*>(xp + 16 * s + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      xf[s][e] = (half_t)fmaf(a[e], rstd, shift);
+      xf[s][4 + e] = (half_t)fmaf(b[e], rstd, shift);
+    }
+  }
+}
+
 // XCD-aware block remap (8 XCDs, blocks dealt round-robin): give each XCD a contiguous
 // chunk of the logical grid so neighbouring tiles share an L2.  Bijective for any nwg.
 static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

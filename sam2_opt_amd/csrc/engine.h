@@ -28,6 +28,8 @@ struct Lin16 {            // MFMA operand: f16 weight [N, K] (nn.Linear layout),
   int N = 0, K = 0;
   size_t lo_off = 0;           // f16x3 mode: the lo plane of w sits lo_off (= N * K) elements behind it; 0 in the f16 mode
   half_t* xs_pack = nullptr;   // same weight in the piece order of the X-stationary GEMM (Hiera stages 1-3, K <= 576)
+  half_t* xs_ln_pack = nullptr;   // ... with the preceding LayerNorm's gain folded in (W diag(g)), for the LN-fused operand load
+  float* b_ln = nullptr;          //     and its bias: W b_LN + b
   half_t* ks_pack = nullptr;   // ... of the accumulator-stationary GEMM (N = 576: stage-3 projection and fc2)
 };
 struct Lin32 {            // tiny fp32 linear for the token-side heads
@@ -47,6 +49,7 @@ struct HieraBlockW {
   Norm n1, n2;
   Lin16 qkv, proj, fc1, fc2, sc;   // sc: dim-change shortcut projection (blocks 2, 8, 44)
   half_t* mlp_pack = nullptr;      // fc1 + fc2 in the fused MLP kernel's piece order (dim_out <= 288), mlp_fused_pack
+  half_t* mlp_ln_pack = nullptr;   // the same with norm2 folded into fc1 (LN-fused operand load); fc1 bias = fc1.b_ln
   float* qscale = nullptr;         // [3*dim_out] column scale of the QKV GEMM: q columns *= 72^-0.5*log2(e), k/v columns 1
 };
 
@@ -118,6 +121,8 @@ struct sam2mi_ctx {
   float* pos_tab = nullptr;    // [G*G, embed] f32, window-major (w = window_spec[0]) token order
   Lin16 neck[4];               // index = level (0: stride 4 ... 3: stride 32)
   Lin16 conv_s0, conv_s1;
+  Lin16 neck_s0, neck_s1;      // conv_s0 o neck[0] (144 -> 32) and conv_s1 o neck[1] (288 -> 64) composed at load time (both are 1x1 convs with
+                               // nothing in between: levels 0 / 1 take no top-down term, fpn_top_down_levels = [2, 3])
   float* sine_pe[3] = {nullptr, nullptr, nullptr};   // NCHW [256, S, S] for S = 256, 128, 64
   float* sine_pe_tok64 = nullptr;                    // the 64x64 table token-major [4096, 256]
   float* no_mem_embed = nullptr;                     // [256]
@@ -174,9 +179,7 @@ struct sam2mi_ctx {
   half_t* ws_att16 = nullptr;   // [M, C]
   half_t* ws_h16 = nullptr;     // [M, 4C]
   half_t* ws_qp16 = nullptr;    // pooled q
-  float* ws_lat[4] = {nullptr, nullptr, nullptr, nullptr};   // neck laterals f32 [M_i, 256]
-  half_t* ws_lat16 = nullptr;   // f16 copy of a lateral (conv_s0 / conv_s1 operand)
-  float* ws_small = nullptr;    // conv_s0 / conv_s1 window-major output
+  float* ws_lat[4] = {nullptr, nullptr, nullptr, nullptr};   // neck outputs f32: [M_0, 32] (conv_s0), [M_1, 64] (conv_s1), laterals [M_2, 256], [M_3, 256]
   size_t ws_tokens = 0;         // max tokens (max_batch * G*G)
 
   // per-frame (B = 1) tracking workspaces
@@ -225,6 +228,7 @@ struct sam2mi_ctx {
   std::map<std::string, ProfAcc> prof_by_kernel;   // the GEMM-family launches again, keyed by kernel instantiation (rocprofv3 names)
   bool use_ks = false;             // accumulator-stationary GEMM for stage-3 fc2 (experimental, SAM2MI_KS=1; parity-tested, not faster end to end)
   bool use_xs = true;              // X-stationary GEMM for K <= 576 linears of the encoder (SAM2MI_NO_XS=1: tiled kernel)
+  bool ln_fuse = true;             // LN1 / LN2 of Hiera blocks computed inside the consumer's operand load (SAM2MI_NO_LN_FUSE=1: separate kernels)
   bool use_fused_mlp = true;       // stages with C <= 288: one fused fc1-GELU-fc2 kernel (SAM2MI_NO_FUSED_MLP=1: two GEMMs, for A/B runs)
 };
 
@@ -243,6 +247,7 @@ int sam2mi_set_error(sam2mi_ctx* ctx, const char* what, const char* detail);
 // engine_core.hip
 void* dalloc(sam2mi_ctx* ctx, size_t bytes);
 int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p);                 // with profiling
+bool xs_eligible(const sam2mi_ctx* ctx, const GemmParams& p);                      // will run_gemm take the X-stationary kernel?
 int run_hiera_attn(sam2mi_ctx* ctx, hipStream_t s, const HieraAttnParams& p);
 int run_mlp_fused(sam2mi_ctx* ctx, hipStream_t s, const MlpFusedParams& p, int C);     // with profiling
 int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p);

@@ -80,9 +80,9 @@ static void prof_end_named(sam2mi_ctx* ctx, ProfAcc& a, const std::string& name,
 }
 
 // X-stationary kernel for the encoder's short-K linears when the operands allow it
-static bool xs_eligible(const sam2mi_ctx* ctx, const GemmParams& p) {
+bool xs_eligible(const sam2mi_ctx* ctx, const GemmParams& p) {
   static const int min_k = getenv("SAM2MI_XS_MINK") ? atoi(getenv("SAM2MI_XS_MINK")) : 0;      // A/B aid
-  return ctx->use_xs && p.K >= min_k && p.xs_pack && p.tile_hint == 0 && p.M >= 16384 && p.lda == p.K && gemm_xs_supported(p.N, p.K) &&
+  return ctx->use_xs && p.K >= min_k && p.xs_pack && p.tile_hint == 0 && p.M >= 16384 && (p.ln_x32 ? p.ln_ld == p.K : p.lda == p.K) && gemm_xs_supported(p.N, p.K) &&
          (p.act == ACT_NONE || p.act == ACT_GELU) && p.rope_cols == 0 && p.res_mod == 0 && !p.outT32 && (p.n_split >= p.N || (p.n_split & 31) == 0) &&
          !(p.out32 && p.out16) && (p.out32 || p.out16) && (!p.res || p.out32) && p.bias &&
          (!p.col_scale || (p.xs_scale_cols > 0 && p.xs_scale_cols <= 576 && (p.xs_scale_cols + 31) / 32 * 32 <= p.n_split));
@@ -108,7 +108,7 @@ int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p_in) {
   }
   if (xs_eligible(ctx, p)) {
     GemmXsParams x{p.A, p.lda, p.xs_pack, p.bias, p.col_scale, p.xs_scale_cols, p.act, p.M, p.N, p.n_split, p.out16, p.ld16, p.outT16, p.ldT16,
-                   p.out32, p.ld32, p.res, p.ldres, 0};
+                   p.out32, p.ld32, p.res, p.ldres, 0, p.ln_x32, p.ln_ld, p.ln_eps};
     hipEvent_t e0, e1;
     if (ctx->prof_on) prof_begin(ctx, ctx->prof_xs, s, e0, e1);
     CHK(gemm_xs_launch(x, p.K, s));
@@ -119,6 +119,7 @@ int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p_in) {
     }
     return 0;
   }
+  if (p.ln_x32) return sam2mi_set_error(ctx, "run_gemm", "LayerNorm-fused operand on a shape the X-stationary kernel does not take");
   hipEvent_t e0, e1;
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_gemm, s, e0, e1);
   CHK(gemm_launch(p, s));
@@ -324,6 +325,7 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   // on the split-operand instantiation of the tiled kernel (gemm2.hip)
   ctx->use_fused_mlp = !ctx->precise && getenv("SAM2MI_NO_FUSED_MLP") == nullptr;
   ctx->use_xs = !ctx->precise && getenv("SAM2MI_NO_XS") == nullptr;
+  ctx->ln_fuse = !ctx->precise && getenv("SAM2MI_NO_LN_FUSE") == nullptr;
   ctx->use_ks = !ctx->precise && getenv("SAM2MI_KS") != nullptr;     // experimental (no end-to-end gain over the tiled kernel on fc2): opt-in
   hipError_t e = gemm_init();
   if (e == hipSuccess) e = flash256_init();
@@ -480,6 +482,45 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
         L->ks_pack = (half_t*)dalloc(ctx, gemm_ks_pack_bytes(L->N, L->K));
         if (!L->ks_pack || gemm_ks_pack(L->w, L->N, L->K, L->K, L->ks_pack, nullptr) != hipSuccess) pk.ok = false;
       }
+      // LN folded into the consumers that load their operand row-wise (X-stationary QKV / fc1, fused MLP):
+      //   W (g * xhat + b_LN) + b = (W diag g) xhat + (W b_LN + b)       (hieradet.py:137,:163: norm1 -> attn.qkv, norm2 -> mlp)
+      auto fold_ln = [&](const std::string& lin, const std::string& nrm, Lin16& folded) {
+        const HostW* w = pk.get(lin + ".weight"); const HostW* bb = pk.get(lin + ".bias");
+        const HostW* g = pk.get(nrm + ".weight"); const HostW* be = pk.get(nrm + ".bias");
+        if (!w || !bb || !g || !be) return;
+        const int N = (int)w->shape[0], K = (int)(w->data.size() / N);
+        std::vector<float> W((size_t)N * K), B(N);
+        for (int n = 0; n < N; ++n) {
+          double acc = bb->data[n];
+          for (int k = 0; k < K; ++k) {
+            W[(size_t)n * K + k] = w->data[(size_t)n * K + k] * g->data[k];
+            acc += (double)w->data[(size_t)n * K + k] * be->data[k];
+          }
+          B[n] = (float)acc;
+        }
+        folded = pk.lin16_raw(W, B, N, K);
+      };
+      Lin16 fc1_folded;
+      if (pk.ok && ctx->ln_fuse) {
+        if (b.qkv.xs_pack && dim == dim_out) {                 // not on dim-change blocks: their LN1 output also feeds the shortcut projection
+          Lin16 f;
+          fold_ln(p + "attn.qkv", p + "norm1", f);
+          b.qkv.xs_ln_pack = (half_t*)dalloc(ctx, gemm_xs_pack_bytes(f.N, f.K));
+          if (!f.w || !b.qkv.xs_ln_pack || gemm_xs_pack(f.w, f.N, f.K, f.K, b.qkv.xs_ln_pack, nullptr) != hipSuccess) pk.ok = false;
+          b.qkv.b_ln = f.b;
+        }
+        if (b.fc1.xs_pack || mlp_fused_supported(b.dim_out)) fold_ln(p + "mlp.layers.0", p + "norm2", fc1_folded);
+        if (b.fc1.xs_pack && fc1_folded.w) {
+          b.fc1.xs_ln_pack = (half_t*)dalloc(ctx, gemm_xs_pack_bytes(fc1_folded.N, fc1_folded.K));
+          if (!b.fc1.xs_ln_pack || gemm_xs_pack(fc1_folded.w, fc1_folded.N, fc1_folded.K, fc1_folded.K, b.fc1.xs_ln_pack, nullptr) != hipSuccess) pk.ok = false;
+          b.fc1.b_ln = fc1_folded.b;
+        }
+      }
+      if (pk.ok && ctx->ln_fuse && mlp_fused_supported(b.dim_out) && fc1_folded.w) {
+        b.mlp_ln_pack = (half_t*)dalloc(ctx, mlp_fused_pack_bytes(b.dim_out));
+        if (!b.mlp_ln_pack || mlp_fused_pack(fc1_folded.w, b.fc2.w, b.dim_out, b.mlp_ln_pack, nullptr) != hipSuccess) pk.ok = false;
+        b.fc1.b_ln = fc1_folded.b;
+      }
       if (pk.ok && !ctx->precise && mlp_fused_supported(b.dim_out)) {     // stages 1-2: weights also in the fused MLP kernel's piece order
         b.mlp_pack = (half_t*)dalloc(ctx, mlp_fused_pack_bytes(b.dim_out));
         if (!b.mlp_pack || mlp_fused_pack(b.fc1.w, b.fc2.w, b.dim_out, b.mlp_pack, nullptr) != hipSuccess) pk.ok = false;
@@ -523,6 +564,32 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
   for (int lvl = 0; lvl < 4; ++lvl) ctx->neck[lvl] = pk.lin16("image_encoder.neck.convs." + std::to_string(3 - lvl) + ".conv");
   ctx->conv_s0 = pk.lin16("sam_mask_decoder.conv_s0");
   ctx->conv_s1 = pk.lin16("sam_mask_decoder.conv_s1");
+  // FPN levels 0 and 1 receive no top-down term (fpn_top_down_levels [2, 3], image_encoder.py:115-125) and only feed
+  // conv_s0 / conv_s1 (sam2_base_official.py:560-565): lateral 1x1 conv and conv_s* are composed in f32 into one linear
+  // map, W = W_s W_lat, b = W_s b_lat + b_s, so the 256-channel 256^2 / 128^2 laterals (537 MB f32 per 8 frames) never exist.
+  {
+    auto compose = [&](const std::string& lat, const std::string& cs, Lin16& out) {
+      const HostW* wl = pk.get(lat + ".weight"); const HostW* bl = pk.get(lat + ".bias");
+      const HostW* ws = pk.get(cs + ".weight");  const HostW* bs = pk.get(cs + ".bias");
+      if (!wl || !bl || !ws || !bs) return;
+      const int mid = (int)wl->shape[0], K = (int)(wl->data.size() / mid), N = (int)ws->shape[0];
+      if ((int)(ws->data.size() / N) != mid) { pk.ok = false; pk.missing += cs + ".weight(shape) "; return; }
+      std::vector<float> W((size_t)N * K), B(N);
+      for (int n = 0; n < N; ++n) {
+        double bacc = bs->data[n];
+        for (int m = 0; m < mid; ++m) bacc += (double)ws->data[(size_t)n * mid + m] * bl->data[m];
+        B[n] = (float)bacc;
+        for (int k = 0; k < K; ++k) {
+          double acc = 0;
+          for (int m = 0; m < mid; ++m) acc += (double)ws->data[(size_t)n * mid + m] * wl->data[(size_t)m * K + k];
+          W[(size_t)n * K + k] = (float)acc;
+        }
+      }
+      out = pk.lin16_raw(W, B, N, K);
+    };
+    compose("image_encoder.neck.convs.3.conv", "sam_mask_decoder.conv_s0", ctx->neck_s0);
+    compose("image_encoder.neck.convs.2.conv", "sam_mask_decoder.conv_s1", ctx->neck_s1);
+  }
   for (int i = 0; i < 3; ++i) {
     const int S = G >> i;
     std::vector<float> pe = sine_pe_nchw(S, S, 256);
@@ -757,9 +824,7 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ARENA16(ctx->ws_att16, T0 * E);
   ARENA16(ctx->ws_h16, T0 * 4 * E);
   ARENA16(ctx->ws_qp16, T0 / 4 * 2 * E);
-  for (int l = 0; l < 4; ++l) ALLOC(ctx->ws_lat[l], float, (T0 >> (2 * l)) * 256);
-  ARENA16(ctx->ws_lat16, T0 * 256);
-  ALLOC(ctx->ws_small, float, T0 * 64);
+  for (int l = 0; l < 4; ++l) ALLOC(ctx->ws_lat[l], float, (T0 >> (2 * l)) * (l == 0 ? 32 : l == 1 ? 64 : 256));   // levels 0 / 1: conv_s0 / conv_s1 outputs
 
   // tracking (B = 1)
   const int NKCAP = 7 * 4096 + 64 * 4 + 4096;         // generous: many conditioning frames are rejected above this

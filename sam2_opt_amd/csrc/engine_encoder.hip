@@ -16,8 +16,16 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   const int M = B * H * W;
   const int C = b.dim, Co = b.dim_out;
   float* x = ctx->ws_x;
-  // 1. LN1
-  CHK(layernorm_launch(x, C, b.n1.w, b.n1.b, 1e-6f, M, C, ctx->ws_a16, C, nullptr, 0, 0, s, ctx->lo16));
+  // 1. LN1 - as a kernel of its own only when the QKV projection cannot normalise its operand rows itself
+  GemmParams qkv_p = lin_params(ctx->ws_a16, C, M, b.qkv);
+  bool fuse1 = false;
+  if (ctx->ln_fuse && b.qkv.xs_ln_pack) {
+    GemmParams t = qkv_p;                     // the launch below, with the LN-fused operand: does the X-stationary kernel take it?
+    t.ln_x32 = x; t.ln_ld = C; t.ln_eps = 1e-6f; t.xs_pack = b.qkv.xs_ln_pack; t.bias = b.qkv.b_ln;
+    t.n_split = 2 * Co; t.col_scale = b.qscale; t.xs_scale_cols = Co; t.out16 = ctx->ws_qk16; t.ld16 = 2 * Co; t.outT16 = ctx->ws_vT16; t.ldT16 = M;
+    fuse1 = xs_eligible(ctx, t);
+  }
+  if (!fuse1) CHK(layernorm_launch(x, C, b.n1.w, b.n1.b, 1e-6f, M, C, ctx->ws_a16, C, nullptr, 0, 0, s, ctx->lo16));
   int Mq = M;
   float* xres = x;           // residual target of the attention projection
   if (b.q_pool) {
@@ -30,7 +38,8 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   }
   // 2. QKV projection: q|k row-major, v transposed (attention consumes V^T tiles)
   {
-    GemmParams p = lin_params(ctx->ws_a16, C, M, b.qkv);
+    GemmParams p = qkv_p;
+    if (fuse1) { p.ln_x32 = x; p.ln_ld = C; p.ln_eps = 1e-6f; p.xs_pack = b.qkv.xs_ln_pack; p.bias = b.qkv.b_ln; }
     p.n_split = 2 * Co;
     p.col_scale = b.qscale;                 // q pre-scaled (f32, before the f16 rounding) for the exp2-domain softmax
     p.xs_scale_cols = Co;                   // k / v columns have scale 1
@@ -102,10 +111,15 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
     CHKI(run_gemm(ctx, s, p));
   }
   if (b.q_pool) { H /= 2; W /= 2; wcur /= 2; }
-  // 5-7. MLP
-  CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s, ctx->lo16));
+  // 5-7. MLP (LN2 inside the consumer's operand load where it reads whole rows)
   if (ctx->use_fused_mlp && b.mlp_pack) {
     // stages 1-2: fc1 -> GELU -> fc2 -> +x in one kernel, the 4C-wide hidden never leaves the CU (mlp_fused.hip)
+    if (ctx->ln_fuse && b.mlp_ln_pack) {
+      MlpFusedParams m{nullptr, Co, b.mlp_ln_pack, b.fc1.b_ln, b.fc2.b, x, Co, Mq, 1e-6f};
+      CHKI(run_mlp_fused(ctx, s, m, Co));
+      return 0;
+    }
+    CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s, ctx->lo16));
     MlpFusedParams m{ctx->ws_a16, Co, b.mlp_pack, b.fc1.b, b.fc2.b, x, Co, Mq};
     CHKI(run_mlp_fused(ctx, s, m, Co));
     return 0;
@@ -113,6 +127,13 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   {
     GemmParams p = lin_params(ctx->ws_a16, Co, Mq, b.fc1);
     p.act = ACT_GELU; p.out16 = ctx->ws_h16; p.ld16 = 4 * Co;
+    bool fuse2 = false;
+    if (ctx->ln_fuse && b.fc1.xs_ln_pack) {
+      GemmParams t = p;
+      t.ln_x32 = x; t.ln_ld = Co; t.ln_eps = 1e-6f; t.xs_pack = b.fc1.xs_ln_pack; t.bias = b.fc1.b_ln;
+      if ((fuse2 = xs_eligible(ctx, t))) p = t;
+    }
+    if (!fuse2) CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s, ctx->lo16));
     CHKI(run_gemm(ctx, s, p));
   }
   {
@@ -155,8 +176,10 @@ static int trunk_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, const
       // lateral 1x1 conv of the FPN on this stage's output (image_encoder.py:113-114)
       const int M = B * H * W;
       CHK(cast_add_launch(ctx->ws_x, b.dim_out, nullptr, 0, 0, 0.f, M, b.dim_out, ctx->ws_a16, b.dim_out, nullptr, 0, s, ctx->lo16));
-      GemmParams p = lin_params(ctx->ws_a16, b.dim_out, M, ctx->neck[level]);
-      p.out32 = ctx->ws_lat[level]; p.ld32 = 256;
+      // levels 0 / 1: the lateral composed with conv_s0 / conv_s1 (32 / 64 channels, compact in ws_lat[level]); levels 2 / 3: lateral
+      const Lin16& L = level == 0 ? ctx->neck_s0 : level == 1 ? ctx->neck_s1 : ctx->neck[level];
+      GemmParams p = lin_params(ctx->ws_a16, b.dim_out, M, L);
+      p.out32 = ctx->ws_lat[level]; p.ld32 = L.N;
       CHKI(run_gemm(ctx, s, p));
       wlev[level] = wcur;
       ++level;
@@ -180,27 +203,16 @@ int encoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, con
     for (int b = 0; b < B; ++b)
       CHK(hipMemcpyAsync(outs[b].feat2, dst + (size_t)b * 4096 * 256, (size_t)4096 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
-  // level 1 (128x128): conv_s1 (256 -> 64) on the lateral, then to row-major
+  // level 1 (128x128, 64 channels) and level 0 (256x256, 32 channels): already conv_s1 / conv_s0 outputs, to row-major
   {
-    const int M = B * (G / 2) * (G / 2);
-    CHK(cast_add_launch(ctx->ws_lat[1], 256, nullptr, 0, 0, 0.f, M, 256, ctx->ws_lat16, 256, nullptr, 0, s, ctx->lo16));
-    GemmParams p = lin_params(ctx->ws_lat16, 256, M, ctx->conv_s1);
-    p.out32 = ctx->ws_small; p.ld32 = 64;
-    CHKI(run_gemm(ctx, s, p));
     float* dst = ctx->ws_x;
-    CHK(permute_tokens_launch(ctx->ws_small, dst, B, G / 2, G / 2, 64, wlev[1], G / 2, nullptr, 0, s));
+    CHK(permute_tokens_launch(ctx->ws_lat[1], dst, B, G / 2, G / 2, 64, wlev[1], G / 2, nullptr, 0, s));
     for (int b = 0; b < B; ++b)
       CHK(hipMemcpyAsync(outs[b].fpn1, dst + (size_t)b * 16384 * 64, (size_t)16384 * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
-  // level 0 (256x256): conv_s0 (256 -> 32)
   {
-    const int M = B * G * G;
-    CHK(cast_add_launch(ctx->ws_lat[0], 256, nullptr, 0, 0, 0.f, M, 256, ctx->ws_lat16, 256, nullptr, 0, s, ctx->lo16));
-    GemmParams p = lin_params(ctx->ws_lat16, 256, M, ctx->conv_s0);
-    p.out32 = ctx->ws_small; p.ld32 = 32;
-    CHKI(run_gemm(ctx, s, p));
     float* dst = ctx->ws_x;
-    CHK(permute_tokens_launch(ctx->ws_small, dst, B, G, G, 32, wlev[0], G, nullptr, 0, s));
+    CHK(permute_tokens_launch(ctx->ws_lat[0], dst, B, G, G, 32, wlev[0], G, nullptr, 0, s));
     for (int b = 0; b < B; ++b)
       CHK(hipMemcpyAsync(outs[b].fpn0, dst + (size_t)b * 65536 * 32, (size_t)65536 * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
   }

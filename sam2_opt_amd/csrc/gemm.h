@@ -31,6 +31,9 @@ struct GemmParams {
   // split-f16 operands (f16x3 precision mode, common.h): lo arrays at these element offsets behind A / W (both or neither);
   // out_lo_off != 0: out16 / outT16 are written as hi + lo
   size_t a_lo_off, w_lo_off, out_lo_off;
+  // LayerNorm fused into the operand load of the X-stationary kernel (gemm_xs.h): A is ignored, the operand is the normalised
+  // row of ln_x32 [M, K] (ln_ld floats per row); xs_pack / bias must be the LN-folded ones.  X-stationary shapes only.
+  const float* ln_x32; int ln_ld; float ln_eps;
 };
 
 static inline GemmParams gemm_params_zero() {

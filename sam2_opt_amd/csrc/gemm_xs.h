@@ -17,6 +17,9 @@ struct GemmXsParams {
   float* out32; int ld32;          // f32 row-major output of columns < n_split (or null)
   const float* res; int ldres;     // f32 residual added to out32 (may alias out32)
   int splits;                      // 0: automatic column split
+  // LayerNorm fused into the operand load (x16 ignored): X = (x32 - mean) * rstd per row, statistics over all K channels of
+  // the row; the weight / bias must carry the affine part (Lin16::xs_ln_pack).  ldx32 % 4 == 0.
+  const float* ln_x32; int ldx32; float ln_eps;
 };
 bool gemm_xs_supported(int N, int K);
 size_t gemm_xs_pack_bytes(int N, int K);

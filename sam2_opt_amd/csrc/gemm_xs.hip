@@ -63,7 +63,9 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams 
 
   // X fragments: X[token fr][16 s + 8 fh + e]; rows past M are clamped (never stored)
   half8 xf[KS];
-  {
+  if (p.ln_x32) {                        // wave-uniform: LayerNorm of the f32 residual-stream row, fused into the load
+    ln_row_fragments<KS>(p.ln_x32 + (size_t)min(tok0 + fr, p.M - 1) * p.ldx32 + fh * 8, p.ln_eps, xf);
+  } else {
     const half_t* xp = p.x16 + (size_t)min(tok0 + fr, p.M - 1) * p.ldx + fh * 8;
 #pragma unroll
     for (int s = 0; s < KS; ++s) xf[s] = *reinterpret_cast<const half8*>(xp + s * 16);
@@ -307,7 +309,7 @@ hipError_t gemm_xs_pack(const half_t* w, int N, int K, int ldw, half_t* wpack, h
 
 hipError_t gemm_xs_launch(const GemmXsParams& p, int K, hipStream_t s) {
   if (p.M <= 0) return hipSuccess;
-  if (!gemm_xs_supported(p.N, K) || (p.ldx & 7) || (p.n_split < p.N && (p.n_split & 31)) || !p.bias) return hipErrorInvalidValue;
+  if (!gemm_xs_supported(p.N, K) || (!p.ln_x32 && (p.ldx & 7)) || (p.ln_x32 && (p.ldx32 & 3)) || (p.n_split < p.N && (p.n_split & 31)) || !p.bias) return hipErrorInvalidValue;
   if (p.n_split < p.N && (!p.outT16 || (p.ldT16 & 3))) return hipErrorInvalidValue;
   if (p.col_scale && (p.scale_cols <= 0 || p.scale_cols > MAX_SCALE || (p.scale_cols + 31) / 32 * 32 > p.n_split)) return hipErrorInvalidValue;
   if (p.out16 && (p.ld16 & 7)) return hipErrorInvalidValue;

@@ -9,6 +9,8 @@ struct MlpFusedParams {
   const float* b2;              // [C]
   float* x32; int ld32;         // residual stream [M, C] f32, updated in place; ld32 % 4 == 0
   int M;
+  float ln_eps;                 // > 0: LayerNorm fused into the operand load - x16 is ignored, X = normalised rows of x32 (the
+                                // LN2 input IS the residual stream), and wpack / b1 must carry the affine part (see gemm_xs.h)
 };
 bool mlp_fused_supported(int C);                     // C in {144, 288}
 // Re-orders fc1 [4C, C] and fc2 [C, 4C] (f16, nn.Linear layout) into the LDS-DMA piece stream of the kernel; once per block.

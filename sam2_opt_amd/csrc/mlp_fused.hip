@@ -95,9 +95,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpFusedParams 
   half8 xf[TN][KS];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
-    const half_t* xp = p.x16 + (size_t)min(tok0 + 32 * tn + fr, p.M - 1) * p.ldx + fh * 8;
+    const size_t row = (size_t)min(tok0 + 32 * tn + fr, p.M - 1);
+    if (p.ln_eps > 0.f) {                    // wave-uniform: LN2 fused into the load - X = normalised rows of the residual stream
+      ln_row_fragments<KS>(p.x32 + row * p.ld32 + fh * 8, p.ln_eps, xf[tn]);
+    } else {
+      const half_t* xp = p.x16 + row * p.ldx + fh * 8;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) xf[tn][s] = *reinterpret_cast<const half8*>(xp + s * 16);
+      for (int s = 0; s < KS; ++s) xf[tn][s] = *reinterpret_cast<const half8*>(xp + s * 16);
+    }
   }
   for (int i = tid; i < H4; i += 256) bias_lds[i] = p.b1[i];
   __syncthreads();                           // bias table visible (also retires the X loads)

@@ -227,7 +227,7 @@ class SAM2VideoPredictor:
         main = torch.cuda.current_stream(self.device)
         st["stream"] = main
         foreign = set()                                         # streams of OTHER states whose cached frames get evicted
-        while len(self._free_feat_slots) < len(idxs):          # evict the least recently used cached frames (of any state)
+        while len(self._free_feat_slots) < len(idxs):          # evict the oldest cached frames (of any state; first in, first out)
             key_old = next(k for k in self._feat_lru if k != (id(st), keep))       # never the frame the caller is about to use
             st_old = self._feat_lru.pop(key_old)
             t_old = key_old[1]
@@ -269,7 +269,6 @@ class SAM2VideoPredictor:
         m = st["feat_slot_of_frame"]
         if frame_idx not in m:
             self._encode_batch(st, frame_idx, forward, side=False)
-        self._feat_lru.move_to_end((id(st), frame_idx))          # most recently used
         ev = st["feat_events"].pop(frame_idx, None)
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)

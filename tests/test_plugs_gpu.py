@@ -178,3 +178,35 @@ def test_prompt_encoder_points_boxes_masks(eng):
     sp, de = eng.prompt_encoder_full(pts, None, randn(77, 2, 1, 256, 256, scale=3.0).cuda())
     chk("plug/points_mask/sparse", sp, 1e-4)
     chk("plug/points_mask/dense", de, 1e-4)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 3, 9, 23])
+def test_hiera_block_batch8_ln_fused(sd_large, cfg_large, oracle_enc, idx):
+    """The benchmark's batch of 8 frames takes the X-stationary / fused-MLP kernels with LayerNorm INSIDE their operand
+    load (norm1 -> QKV, norm2 -> fc1; gain / bias folded into the packed weights): one MultiScaleBlock on 8 distinct inputs vs
+    the oracle, and vs the same engine with the fusion switched off (separate LayerNorm kernels)."""
+    import os
+    from oracle import sam2_ref as R
+    from sam2_opt_amd.config import hiera_block_specs
+    from sam2_opt_amd.native import Engine
+    _, _, blocks = oracle_enc
+    x1 = blocks[idx - 1]
+    g = torch.Generator().manual_seed(idx)
+    x8 = torch.cat([x1 * (0.7 + 0.1 * i) + 0.05 * i * torch.randn(x1.shape, generator=g) for i in range(8)], dim=0).contiguous()
+    spec = [s for s in hiera_block_specs(cfg_large) if s["idx"] == idx][0]
+    with torch.inference_mode():
+        ref = R.hiera_block(x8, sd_large, spec)
+    outs = {}
+    for fused in (True, False):
+        if not fused:
+            os.environ["SAM2MI_NO_LN_FUSE"] = "1"
+        try:
+            e8 = Engine("large", state_dict=sd_large, max_batch=8)
+        finally:
+            os.environ.pop("SAM2MI_NO_LN_FUSE", None)
+        try:
+            outs[fused] = e8.debug_hiera_block(idx, x8.cuda(), ref.shape).cpu()
+        finally:
+            e8.close()
+        check(f"hiera block {idx} batch 8 ({'LN fused' if fused else 'separate LN'})", outs[fused], ref, 5e-3, 2e-3)
+    check(f"hiera block {idx} batch 8 fused vs separate LN", outs[True], outs[False], 4e-3, 1.5e-3)

@@ -299,11 +299,12 @@ def test_multi_object_matches_reference_golden(sd_large, tag):
     from sam2_opt_amd.video_predictor import SAM2VideoPredictor
     g = _golden("large_multi8.npz")
     objs = (1, 2, 3) if tag == "B" else (1, 2)
-    pred = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4, non_overlap_masks=(tag == "C"))
+    # C: the non-overlap constraint is an argmax over objects - where two objects' logits are close (their masks overlap on
+    # this synthetic clip) an error of 2e-3 flips the winner and the loser drops to -10 (measured: 2 % of the pixels in the f16
+    # mode).  The scenario therefore runs in the f16x3 mode (errors ~5e-6), with 0.1 % of the samples set aside for exact ties.
+    pred = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4, non_overlap_masks=(tag == "C"), precision="f16x3" if tag == "C" else "f16")
     try:
-        # C: where two objects' logits tie within the f16 error the argmax of the non-overlap constraint may flip (measured
-        # on 6e-4 of the pixels): 0.2 % outliers are set aside for the video-res masks, the stored low-res logits are exact
-        w = _Worst(g, outlier_frac=2e-3 if tag == "C" else 0.0)
+        w = _Worst(g, tol=(1e-3, 1e-3, 1e-3), outlier_frac=1e-3) if tag == "C" else _Worst(g)
         st = pred.init_state(frames_u8=synthetic_frames_u8(seed=8, num_frames=MULTI_FRAMES), video_height=1024, video_width=1024)
         for oid in objs:
             fr, pt = MULTI_CLICKS[oid]
@@ -487,3 +488,33 @@ def test_one_predictor_two_threads_two_streams(sd_large):
                     assert torch.equal(a, b), (rep, i)
     finally:
         pred.release()
+
+
+@pytest.mark.parametrize("precision,tol", [("f16", 3e-3), ("f16x3", 1e-4)])
+def test_route_a_plug_level_loop_matches_reference_golden(sd_large, cfg_large, precision, tol):
+    """Route A (the drop-in route: a torch host loop around the five plug-level C-ABI entry points in the reference's tensor
+    layouts, sam2_opt_amd/route_a.py) on the first 12 frames of the golden clip: every pixel of the low-res logits vs the REAL
+    reference (tests/golden/large_video24_full.npz)."""
+    from sam2_opt_amd.route_a import PlugLevelTracker
+    from sam2_opt_amd.synthetic import normalize_frames, synthetic_frames_u8
+    g = _golden("large_video24_full.npz")
+    T = 12
+    frames = normalize_frames(synthetic_frames_u8(seed=2, num_frames=24), cfg_large)[:T].cuda()
+    trk = PlugLevelTracker("large", state_dict=sd_large, precision=precision)
+    try:
+        trk.start(frames, CLICK)
+        worst = [0.0, 0.0, 0.0]
+        n = 0
+        for t, low in trk.propagate():
+            got, ref = low.float().cpu().numpy(), g[f"f{t}/pred_masks"]
+            m = float(np.abs(got - ref).max() / np.abs(ref).max())
+            l2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            dis = float(((got > 0) != (ref > 0)).mean())
+            worst = [max(a, b) for a, b in zip(worst, (m, l2, dis))]
+            n += 1
+        assert n == T
+        print(f"[parity] route A ({precision}) vs reference, {T} frames, all low-res pixels: max_rel={worst[0]:.3e} l2={worst[1]:.3e} "
+              f"pixel disagreement={worst[2]:.3e}", flush=True)
+        assert worst[0] <= tol and worst[1] <= tol and worst[2] <= max(tol, 1e-3), worst
+    finally:
+        trk.release()
