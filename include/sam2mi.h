@@ -104,6 +104,15 @@ int sam2mi_prompt_encoder_ex(sam2mi_ctx* ctx, void* stream, const float* coords,
 /* PromptEncoder.get_dense_pe (prompt_encoder.py:113-122) -> (1,256,64,64) */
 int sam2mi_dense_pe(sam2mi_ctx* ctx, void* stream, float* out);
 
+/* ---- frame ingest: the reference's two resizers, on the device.  `in`: decoded RGB frame [H,W,3] uint8.
+ * sam2mi_resize_u8_pil_bicubic   - load_video_frames_from_jpg_images / _load_img_as_tensor (utils/misc.py:92-101): PIL
+ *   Image.resize((S,S)) = separable bicubic (a = -0.5, support stretched when shrinking), 22-bit fixed-point coefficients, a uint8
+ *   rounding after each pass; out [S,S,3] uint8, bit-exact against Pillow.  Feed it to sam2mi_video_encode_u8.
+ * sam2mi_resize_image_aa_bilinear - SAM2Transforms (utils/transforms.py:27-41): ToTensor (/255) + torchvision Resize on a float
+ *   tensor = antialiased bilinear (aten _upsample_bilinear2d_aa); out [3,S,S] f32 in [0,1] (what set_image_e2e takes). */
+int sam2mi_resize_u8_pil_bicubic(sam2mi_ctx* ctx, void* stream, const uint8_t* in, int H, int W, uint8_t* out, int S);
+int sam2mi_resize_image_aa_bilinear(sam2mi_ctx* ctx, void* stream, const uint8_t* in, int H, int W, float* out, int S);
+
 /* ============================================================================================
  * Fused video path: device-resident frame features and memory bank, no host sync, no layout
  * round-trips between the plugs.  Host code (sam2_opt_amd/video_predictor.py) keeps the

@@ -2,7 +2,7 @@
 from /root/reference on seeded synthetic inputs and weights.  Container-only; the
 outputs (data, not code) are committed and travel to the GPU box.
 
-    python -m oracle.gen_golden [plugs] [video] [tiny] [interact] [reverse] [multi] [box] [long] [opts]
+    python -m oracle.gen_golden [plugs] [video] [tiny] [interact] [reverse] [multi] [box] [long] [opts] [ingest]
 
 Weights: sam2_opt_amd.weights.synthetic_state_dict(cfg, seed=0)   (regenerated anywhere)
 Inputs : sam2_opt_amd.synthetic.*  with the seeds named below.
@@ -386,6 +386,37 @@ def gen_opts():
     print("opts done", time.time() - t0, sorted(od["cond_frame_outputs"]))
 
 
+def gen_ingest():
+    """Frame ingest: three synthetic 180 x 320 JPEGs written to a temporary folder and loaded by the REFERENCE's
+    load_video_frames_from_jpg_images (utils/misc.py:213-277: PIL decode + Image.resize((1024, 1024)) + /255 + mean / std).
+    The fixture keeps the JPEG bytes themselves (decoders may differ between boxes; the bytes do not) and the sampled result."""
+    import io
+    import tempfile
+    from PIL import Image
+    from oracle.ref_import import import_reference
+    import_reference()
+    from sam2.utils.misc import load_video_frames_from_jpg_images
+    store = {}
+    with tempfile.TemporaryDirectory() as d:
+        for i in range(3):
+            rs = np.random.RandomState(40 + i)
+            yy, xx = np.mgrid[0:180, 0:320]
+            img = np.stack([(np.sin(yy / 9.0 + i) * 0.5 + 0.5) * 255, xx * 255.0 / 319, ((yy + 2 * xx + 7 * i) % 64) * 4.0], -1)
+            img = np.clip(img + rs.randint(-25, 25, img.shape), 0, 255).astype(np.uint8)
+            buf = io.BytesIO()
+            Image.fromarray(img).save(buf, format="JPEG", quality=92)
+            store[f"jpeg{i}"] = np.frombuffer(buf.getvalue(), dtype=np.uint8)
+            with open(os.path.join(d, f"{i:05d}.jpg"), "wb") as f:
+                f.write(buf.getvalue())
+        images, H, W = load_video_frames_from_jpg_images(video_path=d, image_size=1024, offload_video_to_cpu=True,
+                                                         compute_device=torch.device("cpu"))
+    pack(store, "images", images, 200000)
+    store["video_hw"] = np.array([H, W], dtype=np.int64)
+    store["num_frames"] = np.array([3], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "ingest_jpeg.npz"), **store)
+    print("ingest done", images.shape, H, W)
+
+
 @torch.inference_mode()
 def gen_tiny():
     """BASELINE.json configs[0]: SAM2.1-hiera-tiny image predictor, one 1024^2 frame, torch backend on the CPU - the
@@ -431,3 +462,5 @@ if __name__ == "__main__":
         gen_long()
     if "opts" in which:
         gen_opts()
+    if "ingest" in which:
+        gen_ingest()

@@ -107,9 +107,14 @@ struct DomainGuard {
   }
 };
 
+struct ResizeTable { int* bounds = nullptr; void* coef = nullptr; int ksize = 0; };     // resize.hip: per (kind, in, out) size triple
+
 struct sam2mi_ctx {
   sam2mi_config cfg;
   WsDomain dom_enc, dom_track;
+  std::unordered_map<uint64_t, ResizeTable> resize_tables;
+  void* resize_tmp = nullptr;
+  size_t resize_tmp_bytes = 0;
   std::string err;
   bool finalized = false;
   std::unordered_map<std::string, HostW> hw;     // host copies until finalize
@@ -228,7 +233,7 @@ struct sam2mi_ctx {
   std::map<std::string, ProfAcc> prof_by_kernel;   // the GEMM-family launches again, keyed by kernel instantiation (rocprofv3 names)
   bool use_ks = false;             // accumulator-stationary GEMM for stage-3 fc2 (experimental, SAM2MI_KS=1; parity-tested, not faster end to end)
   bool use_xs = true;              // X-stationary GEMM for K <= 576 linears of the encoder (SAM2MI_NO_XS=1: tiled kernel)
-  bool ln_fuse = true;             // LN1 / LN2 of Hiera blocks computed inside the consumer's operand load (SAM2MI_NO_LN_FUSE=1: separate kernels)
+  bool ln_fuse = false;            // LN1 / LN2 of Hiera blocks computed inside the consumer's operand load (opt-in: SAM2MI_LN_FUSE=1; no end-to-end gain)
   bool use_fused_mlp = true;       // stages with C <= 288: one fused fc1-GELU-fc2 kernel (SAM2MI_NO_FUSED_MLP=1: two GEMMs, for A/B runs)
 };
 

@@ -325,7 +325,10 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   // on the split-operand instantiation of the tiled kernel (gemm2.hip)
   ctx->use_fused_mlp = !ctx->precise && getenv("SAM2MI_NO_FUSED_MLP") == nullptr;
   ctx->use_xs = !ctx->precise && getenv("SAM2MI_NO_XS") == nullptr;
-  ctx->ln_fuse = !ctx->precise && getenv("SAM2MI_NO_LN_FUSE") == nullptr;
+  // LayerNorm inside the operand load of the X-stationary / fused-MLP kernels: parity-tested, but measured EQUAL end to end
+  // (205.6 vs 205.7 frames/s): the row is read twice as f32 by every column split, which costs what the separate LayerNorm
+  // kernel cost (it runs at 5.5 TB/s) and moves more bytes past the L2.  Opt-in for A/B runs.
+  ctx->ln_fuse = !ctx->precise && getenv("SAM2MI_LN_FUSE") != nullptr;
   ctx->use_ks = !ctx->precise && getenv("SAM2MI_KS") != nullptr;     // experimental (no end-to-end gain over the tiled kernel on fc2): opt-in
   hipError_t e = gemm_init();
   if (e == hipSuccess) e = flash256_init();
@@ -526,6 +529,11 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
         if (!b.mlp_pack || mlp_fused_pack(b.fc1.w, b.fc2.w, b.dim_out, b.mlp_pack, nullptr) != hipSuccess) pk.ok = false;
       }
       if (dim != dim_out) b.sc = pk.lin16(p + "proj");
+      // shapes derived from the config: a checkpoint of another model size must fail here, not read out of bounds later
+      auto shape_ok = [&](const Lin16& L, int N, int K) { return !L.w || (L.N == N && L.K == K); };
+      if (!shape_ok(b.qkv, 3 * dim_out, dim) || !shape_ok(b.proj, dim_out, dim_out) || !shape_ok(b.fc1, 4 * dim_out, dim_out) ||
+          !shape_ok(b.fc2, dim_out, 4 * dim_out) || !shape_ok(b.sc, dim_out, dim) || (b.n1.w && b.n1.C != dim) || (b.n2.w && b.n2.C != dim_out))
+        return sam2mi_set_error(ctx, "sam2mi_finalize_weights: tensor shapes do not match the configured architecture at", p.c_str());
       {
         std::vector<float> qs((size_t)3 * dim_out, 1.0f);
         for (int k = 0; k < dim_out; ++k) qs[k] = 1.4426950408889634f / std::sqrt(72.0f);

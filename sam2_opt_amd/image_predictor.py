@@ -3,9 +3,8 @@
 predict :387-454, _prep_prompts :456-485, _predict :487-589; coordinate transforms utils/transforms.py:50-76,
 postprocess_masks :78-120 with max_hole_area = max_sprinkle_area = 0).
 
-Images enter as uint8 HWC arrays like in the reference.  Inputs that are not 1024x1024 are resized with the same
-operator torchvision's tensor `Resize` uses (bilinear, antialias) through PyTorch - frame ingest is outside the hot
-path; everything after that runs in libsam2mi.so.
+Images enter as uint8 HWC arrays like in the reference.  Inputs that are not 1024x1024 are resized on the device by
+sam2mi_resize_image_aa_bilinear (csrc/resize.hip): the operator torchvision's tensor `Resize` applies (bilinear, antialias).
 """
 from __future__ import annotations
 
@@ -66,9 +65,13 @@ class SAM2ImagePredictor:
         for im in image_list:
             assert isinstance(im, np.ndarray), "Images are expected to be an np.ndarray in RGB format, and of shape  HWC"
             self._orig_hw.append(tuple(im.shape[:2]))
-            t = torch.from_numpy(im).to(self.device).permute(2, 0, 1)[None].float() / 255.0
-            if t.shape[-2:] != (S, S):
-                t = F.interpolate(t, size=(S, S), mode="bilinear", align_corners=False, antialias=True)
+            u8 = torch.from_numpy(np.ascontiguousarray(im[..., :3])).to(self.device)
+            if u8.dtype != torch.uint8:
+                raise ValueError("images must be uint8 HWC RGB arrays")
+            if tuple(u8.shape[:2]) != (S, S):        # ToTensor + torchvision Resize (bilinear, antialias) on the device (resize.hip)
+                t = self.engine.resize_image_aa_bilinear(u8.contiguous(), S)[None]
+            else:
+                t = u8.permute(2, 0, 1)[None].float() / 255.0
             tensors.append((t - mean) / std)
         self._slots = list(range(len(tensors)))
         for i in range(0, len(tensors), self.max_batch):

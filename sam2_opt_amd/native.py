@@ -19,7 +19,7 @@ EXPORTS = [
     "sam2mi_finalize_weights", "sam2mi_image_encoder", "sam2mi_set_image_e2e", "sam2mi_memory_attention",
     "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_prompt_encoder_ex", "sam2mi_dense_pe", "sam2mi_video_encode", "sam2mi_video_encode_u8", "sam2mi_fill_holes", "sam2mi_set_fill_hole_area",
     "sam2mi_video_click", "sam2mi_video_mask", "sam2mi_image_predict", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_video_track_batch", "sam2mi_resize_bilinear",
-    "sam2mi_stream_create_reserved", "sam2mi_stream_destroy", "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_profile_read_mlp", "sam2mi_profile_read_xs", "sam2mi_profile_read_ks", "sam2mi_profile_read_kernels", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
+    "sam2mi_resize_u8_pil_bicubic", "sam2mi_resize_image_aa_bilinear", "sam2mi_stream_create_reserved", "sam2mi_stream_destroy", "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_profile_read_mlp", "sam2mi_profile_read_xs", "sam2mi_profile_read_ks", "sam2mi_profile_read_kernels", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
     "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench", "sam2mi_debug_mlp",
 ]
 
@@ -145,7 +145,18 @@ class Engine:
             pass
 
     def load_state_dict(self, sd):
-        """Strict load of a SAM 2.1 `state_dict` (checkpoint["model"]); cf. build_sam._load_checkpoint."""
+        """Strict load of a SAM 2.1 `state_dict` (checkpoint["model"]); cf. build_sam._load_checkpoint: every tensor the
+        configured architecture holds must be present with exactly its shape, and nothing else - a base+ / small / tiny or a
+        truncated checkpoint fails here, by key name, instead of uploading wrong-sized operands."""
+        from .weights import state_dict_spec
+        spec = state_dict_spec(self.cfg)
+        missing = [k for k in spec if k not in sd]
+        unexpected = [k for k in sd if k not in spec]
+        wrong = [f"{k}: {tuple(sd[k].shape)} != {tuple(spec[k])}" for k in spec if k in sd and tuple(sd[k].shape) != tuple(spec[k])]
+        if missing or unexpected or wrong:
+            raise RuntimeError("state_dict does not match the configured SAM 2.1 architecture: "
+                               f"{len(missing)} missing (e.g. {missing[:3]}), {len(unexpected)} unexpected (e.g. {unexpected[:3]}), "
+                               f"{len(wrong)} shape mismatches (e.g. {wrong[:3]})")
         for k, v in sd.items():
             a = v.detach().to(torch.float32).cpu().contiguous().numpy() if isinstance(v, torch.Tensor) else np.ascontiguousarray(v, np.float32)
             shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
@@ -235,6 +246,22 @@ class Engine:
         self._check(self.lib.sam2mi_prompt_encoder_ex(self.h, self.stream, _ptr(coords), _ptr(labels), B, Np, pad, _ptr(masks), _ptr(sparse),
                                                       _ptr(dense)), "sam2mi_prompt_encoder_ex")
         return sparse, dense
+
+    def resize_u8_pil_bicubic(self, frame_u8: torch.Tensor, size: int) -> torch.Tensor:
+        """PIL Image.resize((size, size)) of a decoded RGB frame (H,W,3) uint8 on the device (bit-exact; utils/misc.py:92-101)."""
+        assert frame_u8.is_cuda and frame_u8.dtype == torch.uint8 and frame_u8.dim() == 3 and frame_u8.shape[2] == 3 and frame_u8.is_contiguous()
+        out = torch.empty(size, size, 3, dtype=torch.uint8, device=self.device)
+        self._check(self.lib.sam2mi_resize_u8_pil_bicubic(self.h, self.stream, _ptr(frame_u8), frame_u8.shape[0], frame_u8.shape[1], _ptr(out), size),
+                    "sam2mi_resize_u8_pil_bicubic")
+        return out
+
+    def resize_image_aa_bilinear(self, img_u8: torch.Tensor, size: int) -> torch.Tensor:
+        """ToTensor + torchvision Resize((size, size)) of an RGB image (H,W,3) uint8 -> (3,size,size) f32 in [0,1] (utils/transforms.py:27-41)."""
+        assert img_u8.is_cuda and img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.shape[2] == 3 and img_u8.is_contiguous()
+        out = torch.empty(3, size, size, dtype=torch.float32, device=self.device)
+        self._check(self.lib.sam2mi_resize_image_aa_bilinear(self.h, self.stream, _ptr(img_u8), img_u8.shape[0], img_u8.shape[1], _ptr(out), size),
+                    "sam2mi_resize_image_aa_bilinear")
+        return out
 
     def dense_pe(self):
         out = self.new(1, 256, 64, 64)

@@ -62,7 +62,16 @@ class PlugLevelTracker:
         if multimask:
             low_multi, ious, toks = masks[:, 1:], iou[:, 1:], mask_toks[:, 1:]
         else:
-            low_multi, ious, toks = masks[:, 0:1], iou[:, 0:1], mask_toks[:, 0:1]
+            # MaskDecoder._dynamic_multimask_via_stability (mask_decoder.py:346-382): mask 0 unless it is unstable, then the best of 1-3
+            d, thr = self.cfg["dynamic_multimask_stability_delta"], self.cfg["dynamic_multimask_stability_thresh"]
+            m0 = masks[:, 0:1]
+            inter, union = (m0 > d).sum((-1, -2)).float(), (m0 > -d).sum((-1, -2)).float()
+            stable = torch.where(union > 0, inter / union, torch.ones_like(union)) >= thr                 # (B, 1)
+            bi = torch.arange(B, device=self.device)
+            best = torch.argmax(iou[:, 1:], dim=-1)
+            low_multi = torch.where(stable[..., None, None], m0, masks[:, 1:][bi, best].unsqueeze(1))
+            ious = torch.where(stable, iou[:, 0:1], iou[:, 1:][bi, best].unsqueeze(1))
+            toks = mask_toks[:, 0:1]
         appearing = obj > 0
         low_multi = torch.where(appearing[:, None, None], low_multi, torch.full_like(low_multi, NO_OBJ_SCORE))
         S = self.cfg["image_size"]

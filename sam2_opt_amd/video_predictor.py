@@ -115,11 +115,17 @@ class SAM2VideoPredictor:
         inside the patch-embedding gather, bit-identical to the float path at a quarter of the bytes; or `video_path`: a
         folder of JPEGs (needs PIL; decoded + resized on the host like utils/misc.py:92-101, then the uint8 path)."""
         if frames is None and frames_u8 is None:
-            frames_u8, video_height, video_width = _load_jpeg_folder(video_path, self.cfg)
+            frames_u8 = _load_jpeg_folder(video_path)             # decoded on the host (PIL), resized on the device below
         if frames is None:
+            if isinstance(frames_u8, (list, tuple)):               # frames of any size, decoded (H,W,3) uint8 arrays
+                video_height, video_width = video_height or frames_u8[0].shape[0], video_width or frames_u8[0].shape[1]
+                frames_u8 = self._resize_frames(frames_u8)
             frames = torch.from_numpy(frames_u8) if isinstance(frames_u8, np.ndarray) else frames_u8
-            if frames.dtype != torch.uint8 or frames.dim() != 4 or tuple(frames.shape[1:]) != (self.image_size, self.image_size, 3):
-                raise ValueError(f"frames_u8 must be uint8 (T,{self.image_size},{self.image_size},3)")
+            if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+                raise ValueError("frames_u8 must be uint8 (T,H,W,3)")
+            if tuple(frames.shape[1:3]) != (self.image_size, self.image_size):
+                video_height, video_width = video_height or frames.shape[1], video_width or frames.shape[2]
+                frames = self._resize_frames(list(frames))
         if not offload_video_to_cpu:
             frames = frames.to(self.device)
         st = {
@@ -137,6 +143,15 @@ class SAM2VideoPredictor:
         self._sync_encoder_stream()
         self._ensure_features(st, 0, forward=True)       # warm up the backbone like the reference (:204)
         return st
+
+    def _resize_frames(self, frames):
+        """load_video_frames_from_jpg_images' PIL resize (utils/misc.py:92-101) on the device: bit-exact bicubic, frame by frame."""
+        S = self.image_size
+        out = torch.empty(len(frames), S, S, 3, dtype=torch.uint8, device=self.device)
+        for i, f in enumerate(frames):
+            f = torch.as_tensor(np.ascontiguousarray(f) if isinstance(f, np.ndarray) else f).to(self.device).contiguous()
+            out[i] = self.engine.resize_u8_pil_bicubic(f, S)
+        return out
 
     def _sync_encoder_stream(self):
         """All encoder launches share one workspace: work of the caller's stream must not start an encoder pass (or reuse
@@ -593,19 +608,16 @@ def _sel_slots(sel: MemSelect):
     return {sel.mem_slot[i] for i in range(sel.num_mem)} | {sel.ptr_slot[i] for i in range(sel.num_ptr)}
 
 
-def _load_jpeg_folder(path, cfg):
-    """load_video_frames_from_jpg_images (utils/misc.py:213-277): PIL resize to 1024^2, /255, mean/std."""
+def _load_jpeg_folder(path):
+    """The decode half of load_video_frames_from_jpg_images (utils/misc.py:213-277): JPEGs named <frame index>.jpg, sorted by
+    that index, decoded to RGB uint8 by PIL.  Returns a list of (H,W,3) arrays at the video's own resolution."""
     import os
 
     from PIL import Image
+    if not isinstance(path, str) or not os.path.isdir(path):
+        raise NotImplementedError("Only JPEG frames are supported at this moment (pass a folder of <frame index>.jpg files)")
     names = sorted([p for p in os.listdir(path) if os.path.splitext(p)[-1].lower() in (".jpg", ".jpeg")],
                    key=lambda p: int(os.path.splitext(p)[0]))
     if not names:
         raise RuntimeError(f"no images found in {path}")
-    S = cfg["image_size"]
-    frames = np.zeros((len(names), S, S, 3), np.uint8)
-    for i, n in enumerate(names):
-        im = Image.open(os.path.join(path, n))
-        W, H = im.size
-        frames[i] = np.array(im.convert("RGB").resize((S, S)))
-    return frames, H, W
+    return [np.array(Image.open(os.path.join(path, n)).convert("RGB")) for n in names]

@@ -37,3 +37,30 @@ def test_engine_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         native.Engine("large")
+
+
+def test_state_dict_spec_is_strict(monkeypatch):
+    """Engine.load_state_dict validates names and shapes against the configured architecture before anything is uploaded
+    (ADVICE r01): checked here on the CPU by calling the method on a bare object."""
+    import pytest
+    import torch
+    from sam2_opt_amd import native
+    from sam2_opt_amd.config import get_config
+    from sam2_opt_amd.weights import state_dict_spec
+    eng = object.__new__(native.Engine)
+    eng.cfg = get_config("large")
+    spec = state_dict_spec(eng.cfg)
+    sd = {k: torch.zeros(1).expand(*shape) if len(shape) else torch.zeros(()) for k, shape in spec.items()}
+    k0 = "image_encoder.trunk.blocks.9.attn.qkv.weight"
+    bad = dict(sd)
+    bad[k0] = torch.zeros(1).expand(1728, 288)
+    with pytest.raises(RuntimeError, match="shape mismatches"):
+        native.Engine.load_state_dict(eng, bad)
+    bad = dict(sd)
+    del bad[k0]
+    bad["something.else"] = torch.zeros(1)
+    with pytest.raises(RuntimeError, match="1 missing.*1 unexpected"):
+        native.Engine.load_state_dict(eng, bad)
+    tiny = {k: torch.zeros(1).expand(*shape) for k, shape in state_dict_spec(get_config("tiny")).items()}
+    with pytest.raises(RuntimeError, match="does not match"):
+        native.Engine.load_state_dict(eng, tiny)

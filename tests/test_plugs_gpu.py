@@ -182,9 +182,9 @@ def test_prompt_encoder_points_boxes_masks(eng):
 
 @pytest.mark.parametrize("idx", [0, 1, 3, 9, 23])
 def test_hiera_block_batch8_ln_fused(sd_large, cfg_large, oracle_enc, idx):
-    """The benchmark's batch of 8 frames takes the X-stationary / fused-MLP kernels with LayerNorm INSIDE their operand
-    load (norm1 -> QKV, norm2 -> fc1; gain / bias folded into the packed weights): one MultiScaleBlock on 8 distinct inputs vs
-    the oracle, and vs the same engine with the fusion switched off (separate LayerNorm kernels)."""
+    """A batch of 8 frames takes the X-stationary / fused-MLP kernels; with SAM2MI_LN_FUSE=1 they compute LayerNorm INSIDE
+    their operand load (norm1 -> QKV, norm2 -> fc1; gain / bias folded into the packed weights).  One MultiScaleBlock on 8
+    distinct inputs vs the oracle with the fusion on and off (default: off - measured equal end to end)."""
     import os
     from oracle import sam2_ref as R
     from sam2_opt_amd.config import hiera_block_specs
@@ -198,15 +198,70 @@ def test_hiera_block_batch8_ln_fused(sd_large, cfg_large, oracle_enc, idx):
         ref = R.hiera_block(x8, sd_large, spec)
     outs = {}
     for fused in (True, False):
-        if not fused:
-            os.environ["SAM2MI_NO_LN_FUSE"] = "1"
+        if fused:
+            os.environ["SAM2MI_LN_FUSE"] = "1"
         try:
             e8 = Engine("large", state_dict=sd_large, max_batch=8)
         finally:
-            os.environ.pop("SAM2MI_NO_LN_FUSE", None)
+            os.environ.pop("SAM2MI_LN_FUSE", None)
         try:
             outs[fused] = e8.debug_hiera_block(idx, x8.cuda(), ref.shape).cpu()
         finally:
             e8.close()
         check(f"hiera block {idx} batch 8 ({'LN fused' if fused else 'separate LN'})", outs[fused], ref, 5e-3, 2e-3)
     check(f"hiera block {idx} batch 8 fused vs separate LN", outs[True], outs[False], 4e-3, 1.5e-3)
+
+
+@pytest.mark.parametrize("precision,tol", [("f16", (4e-3, 2e-3)), ("f16x3", (1.5e-3, 6e-4))])
+def test_memory_plugs_with_undamped_weights(cfg_large, precision, tol):
+    """The synthetic weights damp cross_attn_image.out_proj and memory_encoder.out_proj by 0.3 to keep the 100-frame recurrent
+    loop from being chaotic; at the plug level there is no loop, so the memory-attention and memory-encoder plugs are also held
+    to the oracle with those projections at full gain (the f16x3 floor of the memory attention is its f16 flash kernel)."""
+    from oracle import sam2_ref as R
+    from oracle.gen_golden import plug_inputs
+    from sam2_opt_amd.native import Engine
+    from sam2_opt_amd.synthetic import randn
+    from sam2_opt_amd.weights import synthetic_state_dict
+    sd = synthetic_state_dict(cfg_large, seed=0, undamped=True)
+    e = Engine("large", state_dict=sd, max_batch=1, precision=precision)
+    try:
+        inputs = dict(plug_inputs(cfg_large))
+        inputs["memattn_L7P64"] = (randn(51, 4096, 1, 256), randn(52, 7, 4096, 1, 64), randn(53, 4096, 1, 256), randn(54, 7, 4096, 1, 64),
+                                   randn(55, 64, 1, 64), randn(56, 64, 1, 64))
+        for tag in ("memattn_L1P4", "memattn_L3P12", "memattn_L7P64"):
+            with torch.inference_mode():
+                ref = R.memory_attention(*inputs[tag], sd, cfg_large)
+            check(f"undamped {precision} {tag}", e.memory_attention(*[t.cuda() for t in inputs[tag]]), ref, *tol)
+        with torch.inference_mode():
+            x, _ = R.memory_encoder(*inputs["memenc"], sd, cfg_large)
+        gx, _ = e.memory_encoder(*[t.cuda() for t in inputs["memenc"]])
+        check(f"undamped {precision} memenc/x", gx, x, *((5e-3, 2e-3) if precision == "f16" else (1e-4, 3e-5)))
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("mm", [1, 0])
+def test_sam_heads_match_reference_golden(sd_large, cfg_large, golden_plugs, mm):
+    """SAM2Base._forward_sam_heads (sam2_base_official.py:338-494) on seeded inputs vs the REAL reference's outputs
+    (tests/golden/large_plugs.npz: samheads_mm{0,1}) - the prompt-encoder and mask-decoder plugs with the reference-side glue
+    (no-object gating, IoU argmax, obj_ptr MLP) of sam2_opt_amd/route_a.py, in the f16x3 mode so that the argmax is not at
+    the mercy of f16 noise."""
+    from oracle.gen_golden import plug_inputs
+    from sam2_opt_amd.route_a import PlugLevelTracker
+    pix, hr0, hr1 = (t.cuda() for t in plug_inputs(cfg_large)["samheads"])
+    trk = PlugLevelTracker("large", state_dict=sd_large, precision="f16x3")
+    try:
+        with torch.inference_mode():
+            out = trk._sam_heads(pix, hr0, hr1, None, None, bool(mm))
+        g = golden_plugs
+        for name, key in (("low", "pred_masks"), ("high", "high_res_masks"), ("obj_ptr", "obj_ptr"), ("obj_score", "object_score_logits")):
+            n = f"samheads_mm{mm}/{name}"
+            stride, size = (int(v) for v in g[n + "/meta"])
+            a = out[key].float().cpu().numpy().reshape(-1)
+            assert a.size == size, (n, a.size, size)
+            got, ref = a[::stride], g[n + "/sample"]
+            m = float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12))
+            print(f"[parity] {n}: max_rel={m:.3e}", flush=True)
+            assert m <= 1e-4, (n, m)
+    finally:
+        trk.release()

@@ -288,23 +288,48 @@ class _Worst:
         assert m <= self.tol[0] and l2 <= self.tol[1] and dis <= self.tol[2], (name, m, l2, dis)
 
 
-@pytest.mark.parametrize("tag", ["A", "B", "C"])
+def test_non_overlap_constraint_matches_reference_golden(predictor):
+    """non_overlap_masks (SAM2Base._apply_non_overlapping_constraints, sam2_base_official.py:1191-1209, applied by
+    _get_orig_video_res_output :489-509).  On the synthetic clip the two objects' logits lie within 1e-3 of each other on 87 % of
+    the pixels, so the argmax of the constraint is a near-tie almost everywhere and end-to-end pixel parity is meaningless (an
+    error of 5e-6 flips 4 % of the pixels).  The post-process itself is pinned instead: the REFERENCE's low-res logits of
+    scenario A (tests/golden/large_multi8.npz) go through this predictor's video-res path with the constraint on and must give
+    the REFERENCE's scenario-C output (same clip, non_overlap_masks=True)."""
+    g = _golden("large_multi8.npz")
+    st = dict(video_height=1024, video_width=1024)
+    old = predictor.non_overlap_masks
+    predictor.non_overlap_masks = True
+    try:
+        for t in (3, 7):
+            low = torch.from_numpy(np.concatenate([g[f"A/f{t}/obj{k}/pred_masks"] for k in (0, 1)], 0)).cuda()
+            assert np.array_equal(g[f"A/f{t}/obj0/pred_masks"], g[f"C/f{t}/obj0/pred_masks"])       # the constraint does not feed back
+            vm = predictor._video_res(st, low)
+            got, ref = _sample(vm, g, f"C/f{t}/video_res_mask")
+            d = np.abs(got - ref)
+            # an ulp of difference in the bilinear up-sampling flips exact near-ties (|a - b| < 1e-6 on ~0.1 % of the pixels)
+            assert float((d > 1e-4).mean()) <= 5e-3, float((d > 1e-4).mean())
+            raw, _ = _sample(predictor.engine.resize_bilinear(low, (1024, 1024)), g, f"C/f{t}/video_res_mask")
+            assert float((np.abs(raw - ref) > 1e-4).mean()) > 0.3                                   # ... and it is not a no-op
+    finally:
+        predictor.non_overlap_masks = old
+
+
+@pytest.mark.parametrize("tag", ["A", "B", "A/f16x3"])
 def test_multi_object_matches_reference_golden(sd_large, tag):
     """SURVEY 8 f-4 pinned to the REAL reference (tests/golden/large_multi8.npz, oracle/gen_golden.py::gen_multi): the batched
     object pass (sam2mi_video_track_batch) against the reference's per-object B = 1 loop (sam2_video_predictor_official.py:
-    691-725).  A: two objects clicked on frame 0.  B: a third object clicked on frame 2, forward from frame 2, then reverse
-    from frame 2 to 0.  C: A with non_overlap_masks (SAM2Base._apply_non_overlapping_constraints)."""
+    691-725).  A: two objects clicked on frame 0 (also in the f16x3 mode).  B: a third object clicked on frame 2, forward from
+    frame 2, then reverse from frame 2 to 0."""
     from oracle.gen_golden import MULTI_CLICKS, MULTI_FRAMES
     from sam2_opt_amd.synthetic import synthetic_frames_u8
     from sam2_opt_amd.video_predictor import SAM2VideoPredictor
     g = _golden("large_multi8.npz")
+    precise = tag.endswith("f16x3")
+    tag = tag.split("/")[0]
     objs = (1, 2, 3) if tag == "B" else (1, 2)
-    # C: the non-overlap constraint is an argmax over objects - where two objects' logits are close (their masks overlap on
-    # this synthetic clip) an error of 2e-3 flips the winner and the loser drops to -10 (measured: 2 % of the pixels in the f16
-    # mode).  The scenario therefore runs in the f16x3 mode (errors ~5e-6), with 0.1 % of the samples set aside for exact ties.
-    pred = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4, non_overlap_masks=(tag == "C"), precision="f16x3" if tag == "C" else "f16")
+    pred = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4, non_overlap_masks=(tag == "C"), precision="f16x3" if precise else "f16")
     try:
-        w = _Worst(g, tol=(1e-3, 1e-3, 1e-3), outlier_frac=1e-3) if tag == "C" else _Worst(g)
+        w = _Worst(g, tol=(1e-3, 1e-3, 1e-3)) if precise else _Worst(g)
         st = pred.init_state(frames_u8=synthetic_frames_u8(seed=8, num_frames=MULTI_FRAMES), video_height=1024, video_width=1024)
         for oid in objs:
             fr, pt = MULTI_CLICKS[oid]
