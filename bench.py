@@ -131,6 +131,26 @@ def secondary_legs(args, pred, sd, cfg, frames, device):
                                 "f16x3 = split-f16 MFMA operands (3 MFMAs per product), masks within 1e-3 of the reference (measured ~5e-6)")
     finally:
         p2.release()
+    # (c) route A: the drop-in route - a torch host loop around the five plug-level entry points in the reference's tensor
+    # layouts (sam2_opt_amd/route_a.py), what sam2_opt_amd.plugin.speedup_hip(reference_predictor) pays per frame
+    from sam2_opt_amd.route_a import PlugLevelTracker
+    trk = PlugLevelTracker("large", state_dict=sd, device=device, precision=args.precision)
+    try:
+        nA = min(40, frames.shape[0])
+        fa = frames[:nA].to(device)
+        for k in range(2):
+            trk.start(fa, (512.0, 512.0))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = sum(1 for _ in trk.propagate())
+            torch.cuda.synchronize()
+        out["route_a_frames_per_s"] = round(n / (time.perf_counter() - t0), 2)
+        out["route_a_note"] = (f"plug-level route (image encoder, memory attention, prompt encoder, mask decoder, memory encoder called one by one "
+                               f"per frame with NCHW / sequence-first fp32 tensors, torch glue and memory bank): propagate loop over the first {nA} "
+                               f"frames, precision={args.precision}; the headline `value` is the fused route (frame features and memory bank resident "
+                               "in the engine, one C call per tracked frame)")
+    finally:
+        trk.release()
     B = 16
     ip = SAM2ImagePredictor("large", state_dict=sd, max_batch=B, device=device, precision=args.precision)
     try:

@@ -4,11 +4,9 @@
 
 namespace {
 
-// bilinear x4 (align_corners=False, F.interpolate semantics) + sigmoid/binarize + affine
-__global__ void mask_prep_kernel(const float* __restrict__ low, float* __restrict__ out, int binarize, float scale, float bias) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 1024 * 1024) return;
-  const int y = i >> 10, x = i & 1023;
+// mask_for_mem at pixel (y, x) of the 1024^2 grid (sam2_base_official.py:454-459,:1000-1010): bilinear x4 of the 256^2 low-res
+// logits (align_corners=False, F.interpolate semantics), then (binarize ? mask > 0 : sigmoid) * scale + bias
+static __device__ __forceinline__ float mask_prep_value(const float* __restrict__ low, int y, int x, int binarize, float scale, float bias) {
   float sy = (y + 0.5f) * 0.25f - 0.5f, sx = (x + 0.5f) * 0.25f - 0.5f;
   sy = fmaxf(sy, 0.f);
   sx = fmaxf(sx, 0.f);
@@ -18,14 +16,22 @@ __global__ void mask_prep_kernel(const float* __restrict__ low, float* __restric
   const float v = (1.f - ly) * ((1.f - lx) * low[y0 * 256 + x0] + lx * low[y0 * 256 + x1]) +
                   ly * ((1.f - lx) * low[y1 * 256 + x0] + lx * low[y1 * 256 + x1]);
   const float m = binarize ? (v > 0.f ? 1.f : 0.f) : 1.f / (1.f + expf(-v));
-  out[i] = m * scale + bias;
+  return m * scale + bias;
+}
+__global__ void mask_prep_kernel(const float* __restrict__ low, float* __restrict__ out, int binarize, float scale, float bias) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 1024 * 1024) return;
+  out[i] = mask_prep_value(low, i >> 10, i & 1023, binarize, scale, bias);
 }
 
-// one thread = one output pixel, all COUT channels in registers; weights (COUT, CIN, 3, 3) staged in LDS
-template <int CIN, int COUT>
+// one thread = one output pixel, all COUT channels in registers; weights (COUT, CIN, 3, 3) staged in LDS.
+// PREP (CIN == 1, Hin == 1024): `in` is the 256^2 low-res mask and the 1024^2 input pixel is computed on the fly
+// (mask_prep_value), so the 4-MB mask_for_mem tensor is never written or read.
+template <int CIN, int COUT, bool PREP = false>
 __global__ __launch_bounds__(128) void conv3x3s2_ln_gelu_kernel(const float* __restrict__ in, int Hin, const float* __restrict__ w,
                                                                  const float* __restrict__ b, const float* __restrict__ lnw,
-                                                                 const float* __restrict__ lnb, float* out32, half_t* out16, size_t lo_off) {
+                                                                 const float* __restrict__ lnb, float* out32, half_t* out16, size_t lo_off,
+                                                                 int binarize = 0, float scale = 0.f, float bias = 0.f) {
   __shared__ float sw[COUT * CIN * 9];
   for (int i = threadIdx.x; i < COUT * CIN * 9; i += blockDim.x) sw[i] = w[i];
   __syncthreads();
@@ -47,7 +53,7 @@ __global__ __launch_bounds__(128) void conv3x3s2_ln_gelu_kernel(const float* __r
       const float* ip = in + ((size_t)iy * Hin + ix) * CIN;
 #pragma unroll 4
       for (int c = 0; c < CIN; ++c) {
-        const float v = ip[c];
+        const float v = PREP ? mask_prep_value(in, iy, ix, binarize, scale, bias) : ip[c];
 #pragma unroll
         for (int o = 0; o < COUT; ++o) acc[o] += v * sw[(o * CIN + c) * 9 + ky * 3 + kx];
       }
@@ -136,6 +142,13 @@ hipError_t conv3x3s2_ln_gelu_launch(const float* in, int Hin, int CIN, int COUT,
     conv3x3s2_ln_gelu_kernel<16, 64><<<grid, block, 0, s>>>(in, Hin, w, b, lnw, lnb, out32, out16, lo_off);
   else
     return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t conv3x3s2_ln_gelu_from_low_launch(const float* low256, int binarize, float scale, float bias, const float* w, const float* b,
+                                             const float* lnw, const float* lnb, float* out32, hipStream_t s) {
+  const int n = 512 * 512;
+  conv3x3s2_ln_gelu_kernel<1, 4, true><<<dim3((n + 127) / 128), dim3(128), 0, s>>>(low256, 1024, w, b, lnw, lnb, out32, nullptr, 0, binarize, scale, bias);
   return hipGetLastError();
 }
 

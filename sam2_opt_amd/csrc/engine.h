@@ -279,4 +279,6 @@ struct DecoderIn {
   const float* hr1_tok; size_t hr1_stride;                       // [16384,64]
 };
 int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, int T);
-int memenc_forward(sam2mi_ctx* ctx, hipStream_t s, const float* feat2_tok, const float* mask1024, float* out_tok64);
+// mask1024 != null: explicit (already sigmoid-scaled) 1024^2 mask (plug); else low256 + binarize: the fused video path
+int memenc_forward(sam2mi_ctx* ctx, hipStream_t s, const float* feat2_tok, const float* mask1024, float* out_tok64,
+                   const float* low256 = nullptr, int binarize = 0);

@@ -444,9 +444,9 @@ extern "C" int sam2mi_video_encode_memory(sam2mi_ctx* ctx, void* stream, int fea
   if (feat_slot < 0 || feat_slot >= (int)ctx->feats.size() || bank_slot < 0 || bank_slot >= (int)ctx->bank.size())
     return sam2mi_set_error(ctx, __func__, "slot out of range");
   sam2mi_ctx::BankSlot& bk = ctx->bank[bank_slot];
-  // mask_for_mem = (binarize ? mask > 0 : sigmoid(mask)) * 20 - 10 on the 1024^2 bilinear upsampling (:1000-1010)
-  CHK(mask_prep_launch(bk.low_mask, ctx->m_mask, is_mask_from_pts ? 1 : 0, 20.f, -10.f, s));
-  CHKI(memenc_forward(ctx, s, ctx->feats[feat_slot].feat2, ctx->m_mask, ctx->m_out));
+  // mask_for_mem = (binarize ? mask > 0 : sigmoid(mask)) * 20 - 10 on the 1024^2 bilinear upsampling (:1000-1010): evaluated
+  // inside the first conv of the mask down-sampler, the 4-MB tensor is never materialised
+  CHKI(memenc_forward(ctx, s, ctx->feats[feat_slot].feat2, nullptr, ctx->m_out, bk.low_mask, is_mask_from_pts ? 1 : 0));
   // + (1 - appearing) * no_obj_embed_spatial, then the bf16 rounding of the memory bank
   CHK(add_rowvec_launch(ctx->m_out, 64, ctx->no_obj_embed_spatial, 4096, 64, bk.obj_score, s));
   CHK(round_bf16_launch(ctx->m_out, bk.mem, (size_t)4096 * 64, s));

@@ -255,9 +255,11 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
 // ------------------------------------------------------------------ memory encoder
 // MemoryEncoder.inference_memory_torch (modeling/memory_encoder.py:233-241): feat2_tok [4096,256] raw
 // vision features, mask1024 [1024*1024] already sigmoid-scaled -> out_tok64 [4096,64] f32.
-int memenc_forward(sam2mi_ctx* ctx, hipStream_t s, const float* feat2_tok, const float* mask1024, float* out_tok64) {
+int memenc_forward(sam2mi_ctx* ctx, hipStream_t s, const float* feat2_tok, const float* mask1024, float* out_tok64, const float* low256, int binarize) {
   // MaskDownSampler: 4 x (conv3x3 s2 + LN2d + GELU), then 1x1
-  CHK(conv3x3s2_ln_gelu_launch(mask1024, 1024, 1, 4, ctx->md_w[0], ctx->md_b[0], ctx->md_ln[0].w, ctx->md_ln[0].b, ctx->m_c1, nullptr, s, ctx->lo16));
+  if (mask1024) CHK(conv3x3s2_ln_gelu_launch(mask1024, 1024, 1, 4, ctx->md_w[0], ctx->md_b[0], ctx->md_ln[0].w, ctx->md_ln[0].b, ctx->m_c1, nullptr, s, ctx->lo16));
+  else          // fused video path: bilinear x4 + sigmoid / binarise + scale folded into the first conv
+    CHK(conv3x3s2_ln_gelu_from_low_launch(low256, binarize, 20.f, -10.f, ctx->md_w[0], ctx->md_b[0], ctx->md_ln[0].w, ctx->md_ln[0].b, ctx->m_c1, s));
   CHK(conv3x3s2_ln_gelu_launch(ctx->m_c1, 512, 4, 16, ctx->md_w[1], ctx->md_b[1], ctx->md_ln[1].w, ctx->md_ln[1].b, nullptr, ctx->m_c2_16, s, ctx->lo16));
   // conv 16 -> 64 as im2col + MFMA GEMM (K = 144), then LayerNorm2d + GELU
   CHK(im2col3x3s2_launch(ctx->m_c2_16, 256, 16, ctx->m_col16, s, ctx->lo16));

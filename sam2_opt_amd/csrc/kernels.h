@@ -39,6 +39,10 @@ hipError_t mask_prep_launch(const float* low, float* out, int binarize, float sc
 // direct conv 3x3 stride 2 pad 1 on NHWC f32 + bias + LayerNorm2d(eps 1e-6) + GELU; in [Hin*Hin, CIN] -> out [Hout*Hout, COUT]
 hipError_t conv3x3s2_ln_gelu_launch(const float* in, int Hin, int CIN, int COUT, const float* w, const float* b,
                                     const float* lnw, const float* lnb, float* out32, half_t* out16, hipStream_t s, size_t lo_off = 0);
+// first MaskDownSampler stage straight from the 256^2 low-res logits: mask_prep (above) is evaluated per input tap, the 1024^2
+// mask_for_mem tensor never exists; out32 [512*512, 4].  Bit-identical to mask_prep_launch + conv3x3s2_ln_gelu_launch(1 -> 4).
+hipError_t conv3x3s2_ln_gelu_from_low_launch(const float* low256, int binarize, float scale, float bias, const float* w, const float* b,
+                                             const float* lnw, const float* lnb, float* out32, hipStream_t s);
 // im2col for a 3x3 s2 p1 conv on NHWC f16: in [Hin*Hin, CIN] -> A [Hout*Hout, 9*CIN], column (ky*3+kx)*CIN + c
 hipError_t im2col3x3s2_launch(const half_t* in, int Hin, int CIN, half_t* A, hipStream_t s, size_t lo_off = 0);
 // depth-wise 7x7 pad 3 on NHWC f32 [H*H, C]; w [C, 49]

@@ -1,12 +1,18 @@
 #!/bin/bash
-# Round profile recipe (run on the GPU box from the repo root): full bench line, rocprofv3 kernel stats with and without the
-# encoder prefetch stream, and the two PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs) behind roofline.traffic.
-# Outputs land under gpurun_out/; tools/pmc_summary.py + a copy of the *_kernel_stats.csv go to profiles/.
+# Round profile recipe (run on the GPU box from the repo root):  tools/profile_round.sh <tag>   e.g. r02a
+# Full bench line, rocprofv3 kernel stats with and without the encoder prefetch stream, and the two PMC passes (FETCH_SIZE /
+# WRITE_SIZE in SEPARATE runs, counters only - never combined with trace domains) behind roofline.traffic.
+# Outputs land under gpurun_out/<tag>_*; copy what is to be judged into profiles/ afterwards:
+#   python tools/pmc_summary.py gpurun_out/<tag>_pmc_f/*/*counter_collection.csv gpurun_out/<tag>_pmc_w/*/*counter_collection.csv "<label>" profiles/pmc_traffic.json
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python bench.py --steps 5 > gpurun_out/r01d_bench_full.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01d_prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/r01d_prof.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01d_prof_noov -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-overlap > gpurun_out/r01d_prof_noov.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r01d_pmc_f -- python3 bench.py --steps 1 --warmup 0 --frames 16 --no-cpu-baseline --no-roofline --no-overlap > gpurun_out/r01d_pmc_f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/r01d_pmc_w -- python3 bench.py --steps 1 --warmup 0 --frames 16 --no-cpu-baseline --no-roofline --no-overlap > gpurun_out/r01d_pmc_w.log 2>&1
-tail -n 1 gpurun_out/r01d_bench_full.log | cut -c1-300
-ls gpurun_out/r01d_prof/*/ | head
+mkdir -p gpurun_out
+python bench.py --steps 5 > gpurun_out/${TAG}_bench_full.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary > gpurun_out/${TAG}_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof_noov -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-overlap > gpurun_out/${TAG}_prof_noov.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_f -- python3 bench.py --steps 1 --warmup 0 --frames 16 --no-cpu-baseline --no-roofline --no-secondary --no-overlap > gpurun_out/${TAG}_pmc_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_w -- python3 bench.py --steps 1 --warmup 0 --frames 16 --no-cpu-baseline --no-roofline --no-secondary --no-overlap > gpurun_out/${TAG}_pmc_w.log 2>&1
+tail -n 1 gpurun_out/${TAG}_bench_full.log | cut -c1-300
+# keep only the small summaries (the traces themselves are large)
+for d in ${TAG}_prof ${TAG}_prof_noov; do find gpurun_out/$d -name "*kernel_trace.csv" -delete; done
+ls gpurun_out/${TAG}_prof/*/ | head
