@@ -207,6 +207,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=100)
     ap.add_argument("--encode-batch", type=int, default=8)
+    ap.add_argument("--prefetch-depth", type=int, default=1, help="encoder batches the prefetch stream may run ahead of the tracking")
     ap.add_argument("--no-overlap", action="store_true", help="encode and track on one stream (no encoder prefetch stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -240,7 +241,7 @@ def main():
     cfg = get_config("large")
     sd = synthetic_state_dict(cfg, seed=0)
     pred = SAM2VideoPredictor("large", state_dict=sd, encode_batch=args.encode_batch, device=device, overlap_encode=not args.no_overlap,
-                              precision=args.precision)
+                              precision=args.precision, prefetch_depth=args.prefetch_depth)
     frames_u8 = synthetic_frames_u8(seed=D.clip_seed_for_rank(2, rank), num_frames=args.frames)
     frames = normalize_frames(frames_u8, cfg)
     state = pred.init_state(frames=frames, video_height=1024, video_width=1024)       # frames resident in HBM from here on

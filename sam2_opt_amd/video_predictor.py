@@ -47,7 +47,7 @@ class SAM2VideoPredictor:
                  encode_batch: int = 8, bank_slots: int = 384, fill_hole_area: int = 0, non_overlap_masks: bool = False,
                  overlap_encode: bool = True, precision: str = "f16", clear_non_cond_mem_around_input: bool = False,
                  add_all_frames_to_correct_as_cond: bool = False, max_cond_frames_in_attn: int = -1,
-                 memory_temporal_stride_for_eval: int = 1):
+                 memory_temporal_stride_for_eval: int = 1, prefetch_depth: int = 1):
         self.cfg = get_config(model)
         if state_dict is None and ckpt_path is not None:
             # same contract as build_sam._load_checkpoint (build_sam.py:164-174)
@@ -55,8 +55,9 @@ class SAM2VideoPredictor:
         if state_dict is None:
             raise ValueError("state_dict or ckpt_path is required")
         self.encode_batch = int(encode_batch)
+        self.prefetch_depth = max(1, int(prefetch_depth))         # batches the encoder stream may be ahead of the tracking (feature cache = depth + 1 batches)
         self.engine = Engine(self.cfg, state_dict=state_dict, max_batch=self.encode_batch, bank_slots=bank_slots,
-                             feat_slots=max(2 * self.encode_batch, 4), device=device, precision=precision)
+                             feat_slots=max((1 + self.prefetch_depth) * self.encode_batch, 4), device=device, precision=precision)
         self.device = self.engine.device
         self.image_size = self.cfg["image_size"]
         self.num_maskmem = self.cfg["num_maskmem"]
@@ -290,9 +291,10 @@ class SAM2VideoPredictor:
         if self.overlap_encode:
             step = 1 if forward else -1
             t = frame_idx + step
-            while t in m and abs(t - frame_idx) <= self.encode_batch:
+            ahead = self.encode_batch * self.prefetch_depth         # how far the encoder stream may run in front of the tracking
+            while t in m and abs(t - frame_idx) <= ahead:
                 t += step
-            if 0 <= t < st["num_frames"] and abs(t - frame_idx) <= self.encode_batch:
+            if 0 <= t < st["num_frames"] and abs(t - frame_idx) <= ahead:
                 self._encode_batch(st, t, forward, side=True, keep=frame_idx)
         return m[frame_idx]
 

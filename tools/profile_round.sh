@@ -13,6 +13,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_prof_n
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_f -- python3 bench.py --steps 1 --warmup 0 --frames 16 --no-cpu-baseline --no-roofline --no-secondary --no-overlap > gpurun_out/${TAG}_pmc_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_w -- python3 bench.py --steps 1 --warmup 0 --frames 16 --no-cpu-baseline --no-roofline --no-secondary --no-overlap > gpurun_out/${TAG}_pmc_w.log 2>&1
 tail -n 1 gpurun_out/${TAG}_bench_full.log | cut -c1-300
+python tools/trace_gaps.py $(ls gpurun_out/${TAG}_prof_noov/*/*kernel_trace.csv | head -1) 300 > gpurun_out/${TAG}_gaps_noov.txt 2>&1
+cat gpurun_out/${TAG}_gaps_noov.txt
 # keep only the small summaries (the traces themselves are large)
 for d in ${TAG}_prof ${TAG}_prof_noov; do find gpurun_out/$d -name "*kernel_trace.csv" -delete; done
 ls gpurun_out/${TAG}_prof/*/ | head
