@@ -13,6 +13,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long CPU test")
 
 
+def pytest_report_header(config):
+    """Ties a test log to a code state: the hash of the sources libsam2mi.so was built from (sam2_opt_amd/build.py) and whether it
+    still matches the sources in the tree."""
+    try:
+        from sam2_opt_amd.build import built_hash, source_hash
+        b, s_ = built_hash(), source_hash()
+        return f"libsam2mi.so built from source hash {b[:16] or 'n/a'} ({'current' if b == s_ else 'STALE: tree is ' + s_[:16]})"
+    except Exception as e:                       # never block a test run on the header
+        return f"libsam2mi.so source hash unavailable: {e}"
+
+
 @pytest.fixture(scope="session")
 def cfg_large():
     from sam2_opt_amd.config import get_config

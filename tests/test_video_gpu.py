@@ -39,7 +39,14 @@ def test_video_matches_reference_golden(predictor, cfg_large, golden_video):
     print(f"[parity] click frame: max_rel={np.abs(got - ref).max() / np.abs(ref).max():.3e}", flush=True)
     worst = dict(max_rel=0.0, l2=0.0, dis=0.0)
     n = 0
+    gfull = _golden("large_video24_full.npz")
+    worst_full = [0.0, 0.0, 0.0]
     for t, ids, vm in predictor.propagate_in_video(st):
+        od = st["output_dict_per_obj"][0]
+        cur = od["cond_frame_outputs"].get(t) or od["non_cond_frame_outputs"][t]
+        a, b = cur["pred_masks"].float().cpu().numpy(), gfull[f"f{t}/pred_masks"]            # EVERY pixel of the low-res logits
+        worst_full = [max(worst_full[0], float(np.abs(a - b).max() / np.abs(b).max())), max(worst_full[1], float(np.linalg.norm(a - b) / np.linalg.norm(b))),
+                      max(worst_full[2], float(((a > 0) != (b > 0)).mean()))]
         got, ref = _sample(vm, g, f"f{t}/video_res_mask")
         max_rel = float(np.abs(got - ref).max() / np.abs(ref).max())
         l2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
@@ -48,8 +55,10 @@ def test_video_matches_reference_golden(predictor, cfg_large, golden_video):
         worst = dict(max_rel=max(worst["max_rel"], max_rel), l2=max(worst["l2"], l2), dis=max(worst["dis"], dis))
         n += 1
     assert n == T
-    print(f"[parity] video worst over {T} frames: {worst}", flush=True)
+    print(f"[parity] video worst over {T} frames: {worst}; every low-res pixel: max_rel={worst_full[0]:.3e} l2={worst_full[1]:.3e} "
+          f"sign_disagree={worst_full[2]:.3e}", flush=True)
     assert worst["max_rel"] <= 3e-3 and worst["l2"] <= 3e-3 and worst["dis"] <= 1.5e-3, worst
+    assert worst_full[0] <= 3e-3 and worst_full[1] <= 3e-3 and worst_full[2] <= 1.5e-3, worst_full
 
 
 def test_video_intermediates_match_oracle(predictor, sd_large, cfg_large):
