@@ -163,7 +163,7 @@ def secondary_legs(args, pred, sd, cfg, frames, device):
                 t0 = time.perf_counter()
             ip.set_image_batch(imgs)
             for i in range(B):
-                ip._predict(pts[i], lab, None, None, True, True, True, i)
+                ip._predict(pts[i], lab, None, None, True, True, img_idx=i)
         torch.cuda.synchronize()
         out["config5_images_per_s"] = round(2 * B / (time.perf_counter() - t0), 2)
         out["config5_note"] = (f"BASELINE.json configs[4]: {B} synthetic 1024x1024 uint8 images per set_image_batch (host upload + "

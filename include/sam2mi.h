@@ -206,6 +206,11 @@ int sam2mi_video_track_batch(sam2mi_ctx* ctx, void* stream, int feat_slot, int N
  * masks_out (N,1,256,256) + iou_out (N,1). */
 int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int N, int Np,
                          int multimask, float* masks_out, float* iou_out);
+/* The same with the remaining prompt kinds of SAM2ImagePredictor._predict (sam2_image_predictor.py:487-589): mask_inputs
+ * (N,1,256,256) low-res logits of a previous prediction as dense prompt (or NULL), and Np == 0 = no sparse prompt at all
+ * (prompt-free / mask-only prediction: the six output tokens alone). */
+int sam2mi_image_predict_ex(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int N, int Np,
+                            const float* mask_inputs, int multimask, float* masks_out, float* iou_out);
 
 /* Bilinear resize (align_corners=False) of a (H_in,W_in) fp32 map, F.interpolate semantics
  * (_get_orig_video_res_output, sam2_video_predictor_official.py:489-509). */

@@ -692,12 +692,13 @@ class VideoOracle:
 
 
 # ----------------------------------------------------------------------------- image predictor (a18)
-def image_predict(feats, points, labels, multimask_output, orig_hw, sd, cfg, return_logits=True, mask_threshold=0.0):
+def image_predict(feats, points, labels, multimask_output, orig_hw, sd, cfg, return_logits=True, mask_threshold=0.0, mask_input=None):
     """SAM2ImagePredictor._predict (sam2_image_predictor.py:487-589) on `feats` = set_image_e2e output for ONE image.
-    points (B,Np,2) already in 1024-pixel units, labels (B,Np)."""
+    points (B,Np,2) already in 1024-pixel units, labels (B,Np) - a box arrives as its two corners with labels 2 / 3 in front of
+    the user's points (:509-522); mask_input (B,1,256,256) low-res logits as dense prompt."""
     f0, f1, f2 = feats
     B = points.shape[0]
-    sparse, dense = prompt_encoder(points, labels, sd, cfg, None)
+    sparse, dense = prompt_encoder(points, labels, sd, cfg, mask_input)
     low, iou, _, _ = mask_decoder(f2, sparse, dense, f0, f1, multimask_output, B > 1, sd, cfg)
     masks = F.interpolate(low.float(), orig_hw, mode="bilinear", align_corners=False)
     low = torch.clamp(low, -32.0, 32.0)

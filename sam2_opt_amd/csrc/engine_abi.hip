@@ -314,10 +314,12 @@ static int sam_heads_finish(sam2mi_ctx* ctx, hipStream_t s, int multimask, int b
 }
 
 // tokens[n] = [obj_score, iou, mask x4] ++ sparse(points of prompt n + pad)   (mask_decoder.py:186-202), N prompts of Np points
-static int build_tokens(sam2mi_ctx* ctx, hipStream_t s, const float* coords, const int32_t* labels, int N, int Np, int& T) {
+// pad = 1: the prompt encoder's padding point is appended (points without boxes, prompt_encoder.py:220); pad = 0 with Np = 0: no
+// sparse prompt at all (prompt-free prediction: the six output tokens only)
+static int build_tokens(sam2mi_ctx* ctx, hipStream_t s, const float* coords, const int32_t* labels, int N, int Np, int& T, int pad = 1) {
   if (Np + 1 + 6 > 64) return sam2mi_set_error(ctx, "build_tokens", "too many points");
   if (N < 1 || N > DEC_MAX_N) return sam2mi_set_error(ctx, "build_tokens", "prompt batch out of range");
-  T = 6 + Np + 1;
+  T = 6 + Np + pad;
   if (Np > 0) {
     CHK(hipMemcpyAsync(ctx->d_pts, coords, (size_t)N * Np * 2 * sizeof(float), hipMemcpyDefault, s));
     CHK(hipMemcpyAsync(ctx->d_labels, labels, (size_t)N * Np * sizeof(int), hipMemcpyDefault, s));
@@ -325,8 +327,10 @@ static int build_tokens(sam2mi_ctx* ctx, hipStream_t s, const float* coords, con
   for (int n = 0; n < N; ++n) {
     float* tok = ctx->d_sparse + (size_t)n * T * 256;
     CHK(hipMemcpyAsync(tok, ctx->out_tokens, 6 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    CHK(point_embed_launch(Np > 0 ? ctx->d_pts + (size_t)n * Np * 2 : nullptr, Np > 0 ? ctx->d_labels + (size_t)n * Np : nullptr, Np, ctx->gauss,
-                           ctx->point_emb4, ctx->not_a_point, (float)ctx->cfg.image_size, tok + 6 * 256, s));
+    if (pad)      // the embedding kernel writes Np + 1 rows (the padding point last)
+      CHK(point_embed_launch(Np > 0 ? ctx->d_pts + (size_t)n * Np * 2 : nullptr, Np > 0 ? ctx->d_labels + (size_t)n * Np : nullptr, Np, ctx->gauss,
+                             ctx->point_emb4, ctx->not_a_point, (float)ctx->cfg.image_size, tok + 6 * 256, s));
+    else if (Np > 0) return sam2mi_set_error(ctx, "build_tokens", "points without the padding point are not a prompt the predictors produce");
   }
   return 0;
 }
@@ -402,8 +406,8 @@ extern "C" int sam2mi_video_mask(sam2mi_ctx* ctx, void* stream, int feat_slot, c
   return 0;
 }
 
-extern "C" int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int N, int Np,
-                                    int multimask, float* masks_out, float* iou_out) {
+extern "C" int sam2mi_image_predict_ex(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int N, int Np,
+                                       const float* mask_inputs, int multimask, float* masks_out, float* iou_out) {
   REQUIRE_READY();
   DomainGuard guard_(ctx->dom_track, S(stream));
   hipStream_t s = S(stream);
@@ -411,12 +415,19 @@ extern "C" int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot
   if (N < 1) return sam2mi_set_error(ctx, __func__, "no prompts");
   const sam2mi_ctx::FeatSlot& f = ctx->feats[feat_slot];
   CHK(cast_add_launch(f.feat2, 256, ctx->no_mem_embed, 256, 1, 1.f, 4096, 256, nullptr, 0, ctx->t_pix, 256, s, ctx->lo16));
+  const int pad = Np > 0 ? 1 : 0;          // SAM2ImagePredictor._predict passes boxes as points (labels 2 / 3): padded whenever points exist
   // N independent prompts on ONE image (repeat_image, sam2_image_predictor.py:564-579): batched through the decoder
   for (int n0 = 0; n0 < N; n0 += DEC_MAX_N) {
     const int nb = std::min(DEC_MAX_N, N - n0);
     int T = 0;
-    CHKI(build_tokens(ctx, s, coords + (size_t)n0 * Np * 2, labels + (size_t)n0 * Np, nb, Np, T));
-    CHKI(decoder_forward(ctx, s, one_image_in(ctx, f), nb, T));
+    CHKI(build_tokens(ctx, s, Np > 0 ? coords + (size_t)n0 * Np * 2 : nullptr, Np > 0 ? labels + (size_t)n0 * Np : nullptr, nb, Np, T, pad));
+    DecoderIn in = one_image_in(ctx, f);
+    if (mask_inputs) {                     // dense prompt = PromptEncoder._embed_masks(mask_input) per prompt (prompt_encoder.py:178-181)
+      for (int n = 0; n < nb; ++n)
+        CHK(mask_embed_launch(mask_inputs + (size_t)(n0 + n) * 65536, ctx->mask_embed, ctx->d_dense + (size_t)n * 4096 * 256, s));
+      in.dense_tok = ctx->d_dense; in.dense_rows = 4096; in.dense_stride = (size_t)4096 * 256;
+    }
+    CHKI(decoder_forward(ctx, s, in, nb, T));
     if (multimask) {
       if (masks_out)
         CHK(hipMemcpy2DAsync(masks_out + (size_t)n0 * 3 * 65536, (size_t)3 * 65536 * sizeof(float), ctx->d_masks + 65536, (size_t)4 * 65536 * sizeof(float),
@@ -435,6 +446,11 @@ extern "C" int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot
     }
   }
   return 0;
+}
+
+extern "C" int sam2mi_image_predict(sam2mi_ctx* ctx, void* stream, int feat_slot, const float* coords, const int32_t* labels, int N, int Np,
+                                    int multimask, float* masks_out, float* iou_out) {
+  return sam2mi_image_predict_ex(ctx, stream, feat_slot, coords, labels, N, Np, nullptr, multimask, masks_out, iou_out);
 }
 
 extern "C" int sam2mi_video_encode_memory(sam2mi_ctx* ctx, void* stream, int feat_slot, int bank_slot, int is_mask_from_pts) {

@@ -851,7 +851,7 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ALLOC(ctx->t_opart, float, (size_t)16 * 4096 * 256);
   ALLOC(ctx->d_fill_tmp, float, (size_t)65536);
   ALLOC(ctx->d_mask256, float, (size_t)65536);
-  ALLOC(ctx->d_dense, float, (size_t)4096 * 256);
+  ALLOC(ctx->d_dense, float, (size_t)DEC_MAX_N * 4096 * 256);      // dense prompt embeddings of mask prompts, one per prompt of a decoder batch
   ALLOC(ctx->d_pm10, float, 2);
   ALLOC(ctx->d_flag, int, 2);
   ALLOC(ctx->t_ml, float, (size_t)16 * 4096 * 2);

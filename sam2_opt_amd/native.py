@@ -18,7 +18,7 @@ EXPORTS = [
     "sam2mi_abi_version", "sam2mi_create", "sam2mi_destroy", "sam2mi_last_error", "sam2mi_load_weight",
     "sam2mi_finalize_weights", "sam2mi_image_encoder", "sam2mi_set_image_e2e", "sam2mi_memory_attention",
     "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_prompt_encoder_ex", "sam2mi_dense_pe", "sam2mi_video_encode", "sam2mi_video_encode_u8", "sam2mi_fill_holes", "sam2mi_set_fill_hole_area",
-    "sam2mi_video_click", "sam2mi_video_mask", "sam2mi_image_predict", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_video_track_batch", "sam2mi_resize_bilinear",
+    "sam2mi_video_click", "sam2mi_video_mask", "sam2mi_image_predict", "sam2mi_image_predict_ex", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_video_track_batch", "sam2mi_resize_bilinear",
     "sam2mi_resize_u8_pil_bicubic", "sam2mi_resize_image_aa_bilinear", "sam2mi_stream_create_reserved", "sam2mi_stream_destroy", "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_profile_read_mlp", "sam2mi_profile_read_xs", "sam2mi_profile_read_ks", "sam2mi_profile_read_kernels", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
     "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench", "sam2mi_debug_mlp",
 ]
@@ -334,20 +334,28 @@ class Engine:
         fo = self._frame_out(outs)
         self._check(self.lib.sam2mi_video_mask(self.h, self.stream, feat_slot, _ptr(mask1024), bank_slot, C.byref(fo)), "sam2mi_video_mask")
 
-    def image_predict(self, feat_slot: int, coords: np.ndarray, labels: np.ndarray, multimask: bool):
-        """coords (N, Np, 2) / labels (N, Np): N independent prompts on one image, one batched decoder pass.
+    def image_predict(self, feat_slot: int, coords, labels, multimask: bool, mask_inputs: Optional[torch.Tensor] = None, num_prompts: int = 1):
+        """coords (N, Np, 2) / labels (N, Np): N independent prompts on one image, one batched decoder pass; `mask_inputs`
+        (N,1,256,256) low-res logits as dense prompts; coords None = no sparse prompt (then N = num_prompts or the mask batch).
         -> masks (N, 3 or 1, 256, 256), iou (N, 3 or 1)."""
-        coords = np.ascontiguousarray(coords, np.float32)
-        labels = np.ascontiguousarray(labels, np.int32)
-        if coords.ndim == 2:
-            coords, labels = coords[None], labels.reshape(1, -1)
-        N, Np = labels.shape
-        assert coords.shape == (N, Np, 2), (coords.shape, labels.shape)
+        if coords is not None:
+            coords = np.ascontiguousarray(coords, np.float32)
+            labels = np.ascontiguousarray(labels, np.int32)
+            if coords.ndim == 2:
+                coords, labels = coords[None], labels.reshape(1, -1)
+            N, Np = labels.shape
+            assert coords.shape == (N, Np, 2), (coords.shape, labels.shape)
+            cp, lp = coords.ctypes.data_as(C.c_void_p), labels.ctypes.data_as(C.c_void_p)
+        else:
+            N, Np, cp, lp = (mask_inputs.shape[0] if mask_inputs is not None else num_prompts), 0, C.c_void_p(0), C.c_void_p(0)
+        if mask_inputs is not None:
+            mask_inputs = mask_inputs.to(self.device, torch.float32).contiguous()
+            if tuple(mask_inputs.shape) != (N, 1, 256, 256):
+                raise ValueError(f"mask_input must be ({N},1,256,256) low-res logits")
         c = 3 if multimask else 1
         masks, iou = self.new(N, c, 256, 256), self.new(N, c)
-        self._check(self.lib.sam2mi_image_predict(self.h, self.stream, feat_slot, coords.ctypes.data_as(C.c_void_p),
-                                                  labels.ctypes.data_as(C.c_void_p), N, Np, int(multimask), _ptr(masks), _ptr(iou)),
-                    "sam2mi_image_predict")
+        self._check(self.lib.sam2mi_image_predict_ex(self.h, self.stream, feat_slot, cp, lp, N, Np, _ptr(mask_inputs), int(multimask), _ptr(masks),
+                                                     _ptr(iou)), "sam2mi_image_predict_ex")
         return masks, iou
 
     def video_encode_memory(self, feat_slot: int, bank_slot: int, is_mask_from_pts: bool):

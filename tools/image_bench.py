@@ -19,7 +19,7 @@ for it in range(3):
     pred.set_image_batch(imgs)
     torch.cuda.synchronize(); t1 = time.perf_counter()
     for i in range(B):
-        pred._predict(pts[i], lab, None, None, True, True, True, i)
+        pred._predict(pts[i], lab, None, None, True, True, img_idx=i)
     torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"iter {it}: set_image_batch {1e3*(t1-t0):.1f} ms, 8 prompts x {B} images {1e3*(t2-t1):.1f} ms -> {B/(t2-t0):.1f} images/s", flush=True)
 pred.release()
