@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F16_TFLOPS = 2500.0                 # dense f16/bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0                   # HBM3E peak (same guide); ridge = 2500e12 / 8e12 = 312 FLOP/B
 CLIP_GFLOP_PROPAGATE = 240450.0          # algorithmic GFLOP of one 100-frame propagate loop
 
 
@@ -290,9 +291,14 @@ def main():
             if v["launches"] == 0 or v["ms"] <= 0:
                 continue
             tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
-            kern[name] = {"achieved": round(tf, 2), "frac": round(tf / PEAK_F16_TFLOPS, 4), "launches": v["launches"],
-                          "gflop_per_launch": round(v["flops"] / v["launches"] / 1e9, 3), "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
-                          "share_of_timed_region": round(v["ms"] * 1e-3 / dt, 3)}
+            gbps = v["bytes"] / (v["ms"] * 1e-3) / 1e9                       # ALGORITHMIC bytes / launch time
+            ai = v["flops"] / max(v["bytes"], 1.0)
+            # which roof is the lower one for this kernel's arithmetic intensity: min(peak MFMA, AI * peak HBM)
+            bound = "hbm" if ai * PEAK_HBM_GBPS * 1e9 < PEAK_F16_TFLOPS * 1e12 else "mfma"
+            kern[name] = {"bound": bound, "achieved": round(tf, 2), "frac": round(tf / PEAK_F16_TFLOPS, 4), "hbm_gbps": round(gbps, 1),
+                          "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4), "flop_per_byte": round(ai, 1), "launches": v["launches"],
+                          "gflop_per_launch": round(v["flops"] / v["launches"] / 1e9, 3), "mb_per_launch": round(v["bytes"] / v["launches"] / 1e6, 1),
+                          "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2), "share_of_timed_region": round(v["ms"] * 1e-3 / dt, 3)}
         dom = max(kern, key=lambda k: kern[k]["share_of_timed_region"])
         fams = {}
         for fam, key in (("gemm_v2_kernel", "gemm"), ("gemm_xs_kernel", "xs"), ("mlp_fused_kernel", "mlp"), ("gemm_ks_kernel", "ks")):
@@ -302,9 +308,16 @@ def main():
                              "share_of_timed_region": round(ms * 1e-3 / dt, 3)}
         tot_ms = sum(pr[f"{k}_ms"] for k in ("gemm", "xs", "mlp", "ks"))
         tot_fl = sum(pr[f"{k}_flops"] for k in ("gemm", "xs", "mlp", "ks"))
+        # the dominant kernel against the roof that bounds it: "hbm" when its algorithmic intensity lies under the ridge
+        # (312 FLOP/B) - achieved = algorithmic GB/s of 8,000 - else "mfma" - achieved = TFLOP/s of 2,500; the other fraction beside it
+        d = kern[dom]
+        hbm = d["bound"] == "hbm"
         roofline = {
-            "bound": "mfma", "kernel": dom, "achieved": kern[dom]["achieved"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-            "frac": kern[dom]["frac"], "traffic": _pmc_traffic(dom),
+            "bound": d["bound"], "kernel": dom, "achieved": d["hbm_gbps"] if hbm else d["achieved"], "peak": PEAK_HBM_GBPS if hbm else PEAK_F16_TFLOPS,
+            "unit": "GB/s" if hbm else "TFLOP/s", "frac": d["hbm_frac"] if hbm else d["frac"], "traffic": _pmc_traffic(dom),
+            "mfma": {"achieved": d["achieved"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": d["frac"]},
+            "hbm": {"achieved": d["hbm_gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": d["hbm_frac"], "flop_per_byte": d["flop_per_byte"],
+                    "algorithmic_mb_per_launch": d["mb_per_launch"]},
             "launches": kern[dom]["launches"], "gflop_per_launch": kern[dom]["gflop_per_launch"], "avg_launch_us": kern[dom]["avg_launch_us"],
             "share_of_timed_region": kern[dom]["share_of_timed_region"],
             "kernels": dict(sorted(kern.items(), key=lambda kv: -kv[1]["share_of_timed_region"])),

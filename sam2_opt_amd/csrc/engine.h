@@ -72,7 +72,7 @@ struct DecLayerW {
 };
 
 struct ProfAcc {
-  double ms = 0, flops = 0;
+  double ms = 0, flops = 0, bytes = 0;     // bytes: ALGORITHMIC HBM bytes (operands read once + outputs written once)
   int64_t launches = 0;
   struct Pending { hipEvent_t first, second; ProfAcc* named; };   // named: the per-instantiation accumulator fed by the same events
   std::vector<Pending> pending;

@@ -69,9 +69,11 @@ static void prof_end(ProfAcc& a, hipStream_t s, hipEvent_t e0, hipEvent_t e1, do
 }
 
 // second accumulator keyed by the kernel instantiation: same events, drained together in sam2mi_profile_read_kernels
-static void prof_end_named(sam2mi_ctx* ctx, ProfAcc& a, const std::string& name, hipStream_t s, hipEvent_t e0, hipEvent_t e1, double flops) {
+static void prof_end_named(sam2mi_ctx* ctx, ProfAcc& a, const std::string& name, hipStream_t s, hipEvent_t e0, hipEvent_t e1, double flops,
+                           double bytes = 0) {
   ProfAcc& k = ctx->prof_by_kernel[name];       // std::map: references stay valid
   k.flops += flops;
+  k.bytes += bytes;
   k.launches += 1;
   hipEventRecord(e1, s);
   a.pending.push_back({e0, e1, &k});
@@ -91,6 +93,21 @@ static bool ks_eligible(const sam2mi_ctx* ctx, const GemmParams& p) {
   return ctx->use_ks && p.ks_pack && p.tile_hint == 0 && p.M >= 16384 && gemm_ks_supported(p.N, p.K) && p.act == ACT_NONE &&
          !p.col_scale && p.rope_cols == 0 && p.res_mod == 0 && p.out32 && !p.out16 && !p.outT16 && !p.outT32 && p.n_split >= p.N && p.bias;
 }
+// algorithmic HBM bytes of one linear: both operands read once (x2 planes in the split mode), every output written once, the
+// f32 residual read once
+static double gemm_algo_bytes(const GemmParams& p) {
+  const double mk = (double)p.M * p.K, nk = (double)p.N * p.K, mn = (double)p.M * p.N;
+  const double planes = p.a_lo_off ? 2.0 : 1.0;
+  double b = (p.ln_x32 ? 4.0 * mk : 2.0 * mk * planes) + 2.0 * nk * planes;
+  const double row_cols = std::min(p.N, p.n_split), t_cols = p.N - row_cols;
+  if (p.out32) b += 4.0 * p.M * row_cols;
+  if (p.out16) b += 2.0 * p.M * row_cols * (p.out_lo_off ? 2.0 : 1.0);
+  if (p.outT16) b += 2.0 * p.M * t_cols * (p.out_lo_off ? 2.0 : 1.0);
+  if (p.outT32) b += 4.0 * p.M * t_cols;
+  if (p.res) b += 4.0 * mn;
+  return b;
+}
+
 int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p_in) {
   GemmParams p = p_in;
   if (ctx->precise) {            // f16x3: split operands (activations: arena lo plane; weights: packed [hi | lo], or an arena buffer)
@@ -103,7 +120,7 @@ int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p_in) {
     hipEvent_t e0, e1;
     if (ctx->prof_on) prof_begin(ctx, ctx->prof_ks, s, e0, e1);
     CHK(gemm_ks_launch(k, s));
-    if (ctx->prof_on) prof_end_named(ctx, ctx->prof_ks, "gemm_ks_kernel<0>", s, e0, e1, 2.0 * p.M * (double)p.N * p.K);
+    if (ctx->prof_on) prof_end_named(ctx, ctx->prof_ks, "gemm_ks_kernel<0>", s, e0, e1, 2.0 * p.M * (double)p.N * p.K, gemm_algo_bytes(p));
     return 0;
   }
   if (xs_eligible(ctx, p)) {
@@ -115,7 +132,7 @@ int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p_in) {
     if (ctx->prof_on) {
       char nm[96];
       snprintf(nm, sizeof(nm), "gemm_xs_kernel<%d, %s, %s, 0>", p.K, p.act == ACT_GELU ? "true" : "false", p.out32 ? "true" : "false");
-      prof_end_named(ctx, ctx->prof_xs, nm, s, e0, e1, 2.0 * p.M * (double)p.N * p.K);
+      prof_end_named(ctx, ctx->prof_xs, nm, s, e0, e1, 2.0 * p.M * (double)p.N * p.K, gemm_algo_bytes(p));
     }
     return 0;
   }
@@ -123,14 +140,16 @@ int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p_in) {
   hipEvent_t e0, e1;
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_gemm, s, e0, e1);
   CHK(gemm_launch(p, s));
-  if (ctx->prof_on) prof_end_named(ctx, ctx->prof_gemm, gemm_v2_kernel_name(p), s, e0, e1, 2.0 * p.M * (double)p.N * p.K);
+  if (ctx->prof_on) prof_end_named(ctx, ctx->prof_gemm, gemm_v2_kernel_name(p), s, e0, e1, 2.0 * p.M * (double)p.N * p.K, gemm_algo_bytes(p));
   return 0;
 }
 int run_mlp_fused(sam2mi_ctx* ctx, hipStream_t s, const MlpFusedParams& p, int C) {
   hipEvent_t e0, e1;
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_mlp, s, e0, e1);
   CHK(mlp_fused_launch(p, C, s));
-  if (ctx->prof_on) prof_end_named(ctx, ctx->prof_mlp, mlp_fused_kernel_name(C), s, e0, e1, 2.0 * 2.0 * p.M * (double)C * (4.0 * C));   // fc1 + fc2
+  // fused MLP: X (f16, or the f32 residual row when LayerNorm is fused) + the f32 residual in and out + both weight matrices
+  if (ctx->prof_on) prof_end_named(ctx, ctx->prof_mlp, mlp_fused_kernel_name(C), s, e0, e1, 2.0 * 2.0 * p.M * (double)C * (4.0 * C),
+                                   (p.ln_eps > 0.f ? 0.0 : 2.0 * p.M * (double)C) + 8.0 * p.M * (double)C + 2.0 * 8.0 * C * (double)C);
   return 0;
 }
 int run_hiera_attn(sam2mi_ctx* ctx, hipStream_t s, const HieraAttnParams& p) {
@@ -405,7 +424,8 @@ extern "C" int sam2mi_profile_read_kernels(sam2mi_ctx* ctx, char* out, int cap) 
   std::string sout;
   for (auto& kv : ctx->prof_by_kernel) {
     char line[256];
-    snprintf(line, sizeof(line), "%s\t%.9f\t%.17g\t%lld\n", kv.first.c_str(), kv.second.ms, kv.second.flops, (long long)kv.second.launches);
+    snprintf(line, sizeof(line), "%s\t%.9f\t%.17g\t%lld\t%.17g\n", kv.first.c_str(), kv.second.ms, kv.second.flops, (long long)kv.second.launches,
+             kv.second.bytes);
     sout += line;
   }
   if ((int)sout.size() + 1 > cap) return -1;

@@ -411,15 +411,16 @@ class Engine:
         return torch.cuda.ExternalStream(h.value, device=self.device)
 
     def profile_read_kernels(self) -> dict:
-        """{kernel instantiation name: dict(ms, flops, launches)} of the GEMM-family launches since profile_enable(True)."""
+        """{kernel instantiation name: dict(ms, flops, launches, bytes)} of the GEMM-family launches since profile_enable(True);
+        bytes = algorithmic HBM bytes (operands read once, outputs written once)."""
         buf = C.create_string_buffer(1 << 16)
         n = self.lib.sam2mi_profile_read_kernels(self.h, buf, len(buf))
         if n < 0:
             raise RuntimeError("sam2mi_profile_read_kernels failed")
         out = {}
         for line in buf.value.decode().splitlines():
-            name, ms, fl, cnt = line.split("\t")
-            out[name] = dict(ms=float(ms), flops=float(fl), launches=int(cnt))
+            name, ms, fl, cnt, by = line.split("\t")
+            out[name] = dict(ms=float(ms), flops=float(fl), launches=int(cnt), bytes=float(by))
         return out
 
     def _prof3(self, name):
