@@ -2,7 +2,7 @@
 from /root/reference on seeded synthetic inputs and weights.  Container-only; the
 outputs (data, not code) are committed and travel to the GPU box.
 
-    python -m oracle.gen_golden [plugs] [video] [tiny] [interact] [reverse] [multi] [box] [long] [opts] [ingest]
+    python -m oracle.gen_golden [plugs] [video] [tiny] [interact] [reverse] [multi] [box] [long] [opts] [ingest] [sizes]
 
 Weights: sam2_opt_amd.weights.synthetic_state_dict(cfg, seed=0)   (regenerated anywhere)
 Inputs : sam2_opt_amd.synthetic.*  with the seeds named below.
@@ -386,6 +386,23 @@ def gen_opts():
     print("opts done", time.time() - t0, sorted(od["cond_frame_outputs"]))
 
 
+@torch.inference_mode()
+def gen_sizes():
+    """The padded-window model sizes (hiera small / base+; tiny has its own end-to-end golden): SAM2Base.inference_image_torch of the
+    REAL reference on the seeded image, synthetic weights of that size."""
+    store = {}
+    img = synthetic_image_normed(seed=1)
+    for name in ("small", "base_plus"):
+        cfg = get_config(name)
+        model = build_reference_model(cfg, "base", synthetic_state_dict(cfg, seed=0))
+        outs = model.inference_image_torch(img)
+        for n, o in zip(("vision_features", "vision_pos_enc0", "vision_pos_enc1", "vision_pos_enc2", "backbone_fpn0", "backbone_fpn1", "backbone_fpn2"), outs):
+            if "pos_enc" not in n:
+                pack(store, f"{name}/{n}", o, 65536)
+        print("sizes", name, "done", flush=True)
+    np.savez_compressed(os.path.join(GOLD, "sizes_encoder.npz"), **store)
+
+
 def gen_ingest():
     """Frame ingest: three synthetic 180 x 320 JPEGs written to a temporary folder and loaded by the REFERENCE's
     load_video_frames_from_jpg_images (utils/misc.py:213-277: PIL decode + Image.resize((1024, 1024)) + /255 + mean / std).
@@ -464,3 +481,5 @@ if __name__ == "__main__":
         gen_opts()
     if "ingest" in which:
         gen_ingest()
+    if "sizes" in which:
+        gen_sizes()

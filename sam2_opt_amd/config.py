@@ -54,6 +54,14 @@ MODEL_CONFIGS = {
     "tiny": dict(_COMMON, name="sam2.1_hiera_tiny", embed_dim=96, num_heads=1,
                  stages=(1, 2, 7, 2), global_att_blocks=(5, 7, 9),
                  window_spec=(8, 4, 14, 7)),
+    # sam2.1_hiera_s.yaml:11-16
+    "small": dict(_COMMON, name="sam2.1_hiera_small", embed_dim=96, num_heads=1,
+                  stages=(1, 2, 11, 2), global_att_blocks=(7, 10, 13),
+                  window_spec=(8, 4, 14, 7)),
+    # sam2.1_hiera_b+.yaml:11-13: everything else is the Hiera default (hieradet.py:175-200)
+    "base_plus": dict(_COMMON, name="sam2.1_hiera_base_plus", embed_dim=112, num_heads=2,
+                      stages=(2, 3, 16, 3), global_att_blocks=(12, 16, 20),
+                      window_spec=(8, 4, 14, 7), window_pos_embed_bkg_spatial_size=(14, 14)),
 }
 
 

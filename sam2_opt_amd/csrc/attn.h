@@ -30,6 +30,19 @@ struct PreciseAttnParams {
 };
 hipError_t precise_attn_launch(const PreciseAttnParams& p, hipStream_t stream);
 
+// ---- Hiera attention for the sizes whose windows are zero-padded (hiera_generic.hip): any head_dim in {56, 72, 96}
+struct GenericAttnParams {
+  const half_t* q; int ldq;     // [num_groups * GQ, ldq] f16, pre-scaled by head_dim^-0.5 * log2(e); head h at columns [h*HD, (h+1)*HD)
+  const half_t* k; int ldk;     // [num_groups * GK, ldk]
+  const half_t* vT; int ldvT;   // V^T [heads*HD, ldvT], column = key row index
+  half_t* o; int ldo;           // [num_groups * GQ, ldo]
+  int heads;
+  int GQ, GK;                   // rows per group (multiples of 32)
+  int wq, wk, vk;               // query i sees key j (inside the group) iff i / wq == j / wk and j % wk < vk
+  int num_groups;
+};
+hipError_t generic_attn_launch(const GenericAttnParams& p, int head_dim, hipStream_t stream);
+
 // ---- single-head d=256 flash attention with split-KV (attn_flash256.hip)
 struct Flash256Params {
   const half_t* q; int ldq;     // [Nq, ldq] f16, RoPE applied and PRE-SCALED by 256^-0.5 * log2(e); Nq % 128 == 0

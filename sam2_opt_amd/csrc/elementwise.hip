@@ -125,7 +125,7 @@ __global__ void cast_add_kernel(const float* __restrict__ a, int lda, const floa
 // U8: img is uint8 [B, S, S, 3] (decoded HWC frames); the /255, -mean, /std of load_video_frames (utils/misc.py:270-276)
 // is applied here in f32, in that order, so the f16 operand is bit-identical to the one built from a normalised f32 frame
 template <bool U8>
-__global__ void im2col_patch_kernel(const void* __restrict__ img_, int B, int S, half_t* __restrict__ A, size_t lo_off) {
+__global__ void im2col_patch_kernel(const void* __restrict__ img_, int B, int S, half_t* __restrict__ A, size_t lo_off, int row_major) {
   const float* img = static_cast<const float*>(img_);
   const uint8_t* img8 = static_cast<const uint8_t*>(img_);
   const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
@@ -140,7 +140,7 @@ __global__ void im2col_patch_kernel(const void* __restrict__ img_, int B, int S,
   // window-major (w = 8) token -> (y, x)
   const int win = t >> 6, in = t & 63;
   const int wpr = G / 8;
-  const int y = (win / wpr) * 8 + (in >> 3), x = (win % wpr) * 8 + (in & 7);
+  const int y = row_major ? t / G : (win / wpr) * 8 + (in >> 3), x = row_major ? t % G : (win % wpr) * 8 + (in & 7);
   half8 out, out_lo;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -276,14 +276,14 @@ hipError_t cast_add_launch(const float* a, int lda, const float* b, int ldb, int
     cast_add_kernel<<<grid1d((size_t)M * C), dim3(256), 0, s>>>(a, lda, b, ldb, bmod, sb, M, C, y16, ldy16, y32, ldy32, lo_off);
   return hipGetLastError();
 }
-hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStream_t s, size_t lo_off) {
+hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStream_t s, size_t lo_off, int row_major) {
   const size_t total = (size_t)B * (S / 4) * (S / 4) * 20;
-  im2col_patch_kernel<false><<<grid1d(total), dim3(256), 0, s>>>(img, B, S, A, lo_off);
+  im2col_patch_kernel<false><<<grid1d(total), dim3(256), 0, s>>>(img, B, S, A, lo_off, row_major);
   return hipGetLastError();
 }
-hipError_t im2col_patch_u8_launch(const uint8_t* img_hwc, int B, int S, half_t* A, hipStream_t s, size_t lo_off) {
+hipError_t im2col_patch_u8_launch(const uint8_t* img_hwc, int B, int S, half_t* A, hipStream_t s, size_t lo_off, int row_major) {
   const size_t total = (size_t)B * (S / 4) * (S / 4) * 20;
-  im2col_patch_kernel<true><<<grid1d(total), dim3(256), 0, s>>>(img_hwc, B, S, A, lo_off);
+  im2col_patch_kernel<true><<<grid1d(total), dim3(256), 0, s>>>(img_hwc, B, S, A, lo_off, row_major);
   return hipGetLastError();
 }
 hipError_t pool_tokens_f32_launch(const float* in, int ldin, float* out, int ldout, int nwin, int w, int C, hipStream_t s) {

@@ -175,6 +175,13 @@ struct sam2mi_ctx {
   float* ws_vT32 = nullptr;
   float* ws_qp32 = nullptr;
 
+  // ---- model family: hiera-large (window spec 8/4/16/8, head_dim 72: windows tile the grid - the window-major path of
+  // engine_encoder.hip) or the padded-window sizes tiny / small / base+ (8/4/14/7, head_dim 96 / 56: hiera_generic.hip)
+  bool generic = false;
+  int head_dim = 72;
+  half_t* ws_w16 = nullptr;    // generic path: LN output gathered into the (padded) window layout
+  half_t* ws_o16 = nullptr;    // generic path: attention output in the window layout
+
   // ---- workspaces (sized for cfg.max_batch frames)
   float* ws_x = nullptr;        // residual stream f32
   float* ws_x2 = nullptr;       // second f32 buffer (shortcut / permute target)
@@ -264,6 +271,7 @@ struct EncOut { float* feat2; float* fpn1; float* fpn0; };   // token-major [B, 
 // img: normalised f32 NCHW, or (img == nullptr) img_u8: decoded uint8 HWC frames normalised on the fly
 int encoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, const EncOut* outs /*[B]*/, const uint8_t* img_u8 = nullptr);
 int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& blk, int B, int& H, int& W, int& wcur);
+int hiera_block_forward_generic(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& blk, int B, int& H, int& W);   // row-major tokens
 
 // engine_track.hip
 constexpr int TRACK_MAX_N = 8;    // objects per batched tracking call (workspace size)

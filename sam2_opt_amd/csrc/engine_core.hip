@@ -459,9 +459,16 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
   Packer pk{ctx};
   const int E = c.embed_dim;
   const int G = c.image_size / 4;
-  if (c.window_spec[0] != 8 || c.window_spec[1] != 4 || c.window_spec[2] != 16 || c.window_spec[3] != 8 || E % 72)
-    return sam2mi_set_error(ctx, "sam2mi_finalize_weights",
-                            "only window_spec (8,4,16,8) with head_dim 72 (hiera-large family) is implemented in the HIP path");
+  ctx->head_dim = c.num_heads > 0 ? E / c.num_heads : 0;
+  const bool large_family = c.window_spec[0] == 8 && c.window_spec[1] == 4 && c.window_spec[2] == 16 && c.window_spec[3] == 8 && ctx->head_dim == 72;
+  ctx->generic = !large_family;
+  if (ctx->generic) {
+    if (c.num_heads <= 0 || E % c.num_heads || (ctx->head_dim != 56 && ctx->head_dim != 72 && ctx->head_dim != 96) || E % 16)
+      return sam2mi_set_error(ctx, "sam2mi_finalize_weights", "head_dim must be 56, 72 or 96 (hiera tiny / small / base+ / large)");
+    for (int i = 0; i < 4; ++i)
+      if (c.window_spec[i] < 2 || c.window_spec[i] > 16) return sam2mi_set_error(ctx, "sam2mi_finalize_weights", "window sizes 2..16 are supported");
+    if (ctx->precise) return sam2mi_set_error(ctx, "sam2mi_finalize_weights", "the f16x3 mode is implemented for hiera-large only");
+  }
 
   // ---- Hiera block table (hieradet.py:243-268)
   {
@@ -556,7 +563,7 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
         return sam2mi_set_error(ctx, "sam2mi_finalize_weights: tensor shapes do not match the configured architecture at", p.c_str());
       {
         std::vector<float> qs((size_t)3 * dim_out, 1.0f);
-        for (int k = 0; k < dim_out; ++k) qs[k] = 1.4426950408889634f / std::sqrt(72.0f);
+        for (int k = 0; k < dim_out; ++k) qs[k] = 1.4426950408889634f / std::sqrt((float)ctx->head_dim);
         b.qscale = dupload(ctx, qs);
       }
       ctx->blocks.push_back(b);
@@ -581,7 +588,7 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
       std::vector<float> tab((size_t)G * G * E);
       for (int y = 0; y < G; ++y)
         for (int x = 0; x < G; ++x) {
-          const int t = tok_of_yx(y, x, G, 8);
+          const int t = ctx->generic ? y * G + x : tok_of_yx(y, x, G, 8);       // generic sizes: plain row-major tokens
           for (int ch = 0; ch < E; ++ch)
             tab[(size_t)t * E + ch] = big[((size_t)ch * G + y) * G + x] + pw->data[((size_t)ch * ws + (y % ws)) * ws + (x % ws)];
         }
@@ -852,6 +859,10 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ARENA16(ctx->ws_att16, T0 * E);
   ARENA16(ctx->ws_h16, T0 * 4 * E);
   ARENA16(ctx->ws_qp16, T0 / 4 * 2 * E);
+  if (ctx->generic) {
+    ARENA16(ctx->ws_w16, T0 * 2 * E);
+    ARENA16(ctx->ws_o16, T0 * 2 * E);
+  }
   for (int l = 0; l < 4; ++l) ALLOC(ctx->ws_lat[l], float, (T0 >> (2 * l)) * (l == 0 ? 32 : l == 1 ? 64 : 256));   // levels 0 / 1: conv_s0 / conv_s1 outputs
 
   // tracking (B = 1)

@@ -163,6 +163,13 @@ extern "C" int sam2mi_debug_hiera_block(sam2mi_ctx* ctx, void* stream, int block
   int H = G, W = G;
   int w = b.window > 0 ? b.window : 16;
   if (B > ctx->cfg.max_batch) return sam2mi_set_error(ctx, __func__, "batch exceeds max_batch");
+  if (ctx->generic) {                      // padded-window sizes: row-major tokens in and out
+    CHK(hipMemcpyAsync(ctx->ws_x, x_nhwc, (size_t)B * H * W * b.dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CHKI(hiera_block_forward_generic(ctx, s, b, B, H, W));
+    CHK(hipMemcpyAsync(out_nhwc, ctx->ws_x, (size_t)B * H * W * b.dim_out * sizeof(float), hipMemcpyDeviceToDevice, s));
+    CHK(hipStreamSynchronize(s));
+    return 0;
+  }
   CHK(permute_tokens_launch(x_nhwc, ctx->ws_x, B, H, W, b.dim, W, w, nullptr, 0, s));
   CHKI(hiera_block_forward(ctx, s, b, B, H, W, w));
   CHK(permute_tokens_launch(ctx->ws_x, out_nhwc, B, H, W, b.dim_out, w, W, nullptr, 0, s));

@@ -144,6 +144,87 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   return 0;
 }
 
+static inline int pad32(int v) { return (v + 31) / 32 * 32; }
+// rows one window occupies in the window layout: its w*w tokens, packed (32 % T == 0: several windows per 32-row group, separated
+// by the block-diagonal mask) or padded to a multiple of 32 (the padding rows are masked out as keys, dropped as queries)
+static inline int window_rows(int T) { return (T % 32 == 0 || 32 % T == 0) ? T : pad32(T); }
+
+// One MultiScaleBlock (hieradet.py:134-166) of the padded-window model sizes on plain row-major tokens [B, H, W, C]; see
+// hiera_generic.hip for the window layout.
+int hiera_block_forward_generic(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, int B, int& H, int& W) {
+  const int M = B * H * W, C = b.dim, Co = b.dim_out, hd = ctx->head_dim;
+  float* x = ctx->ws_x;
+  if (H != W) return sam2mi_set_error(ctx, "hiera_block_forward_generic", "square token grids only");
+  CHK(layernorm_launch(x, C, b.n1.w, b.n1.b, 1e-6f, M, C, ctx->ws_a16, C, nullptr, 0, 0, s));
+  if (b.q_pool) {
+    // shortcut = maxpool2x2(proj(LN(x)))   (hieradet.py:139-140); the whole image is one "window" of the pooling kernel
+    GemmParams p = lin_params(ctx->ws_a16, C, M, b.sc);
+    p.out32 = ctx->ws_x2; p.ld32 = Co;
+    CHKI(run_gemm(ctx, s, p));
+    CHK(pool_tokens_f32_launch(ctx->ws_x2, Co, x, Co, B, W, Co, s));
+  }
+  // ---- windows
+  const int w = b.window;
+  const bool global = w == 0;
+  const int nW = global ? 1 : (H + w - 1) / w;
+  const int T = global ? H * W : w * w, wk = global ? T : window_rows(T);
+  const int nwin = B * nW * nW, Mw = nwin * wk;
+  if (b.q_pool && (global || (w & 1))) return sam2mi_set_error(ctx, "hiera_block_forward_generic", "query pooling needs an even window");
+  const half_t* aw = ctx->ws_a16;
+  if (!global) {
+    CHK(window_gather_launch(ctx->ws_a16, ctx->ws_w16, B, H, W, C, w, nW, wk, s));
+    aw = ctx->ws_w16;
+  }
+  {
+    GemmParams p = lin_params(aw, C, Mw, b.qkv);
+    p.n_split = 2 * Co; p.col_scale = b.qscale; p.xs_scale_cols = Co;
+    p.out16 = ctx->ws_qk16; p.ld16 = 2 * Co; p.outT16 = ctx->ws_vT16; p.ldT16 = Mw;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  GenericAttnParams a;
+  memset(&a, 0, sizeof(a));
+  a.k = ctx->ws_qk16 + Co; a.ldk = 2 * Co; a.vT = ctx->ws_vT16; a.ldvT = Mw; a.heads = b.heads; a.vk = T;
+  int wq = wk, we = global ? W : w;                 // rows per window of the query side, edge of the query window
+  if (!b.q_pool) {
+    a.q = ctx->ws_qk16; a.ldq = 2 * Co;
+  } else {
+    const int hw = w / 2;
+    wq = window_rows(hw * hw);
+    we = hw;
+    CHK(window_pool_q_launch(ctx->ws_qk16, 2 * Co, ctx->ws_qp16, Co, nwin, w, wk, wq, s));
+    a.q = ctx->ws_qp16; a.ldq = Co;
+  }
+  if (wq >= 32) { a.GQ = wq; a.GK = wk; a.num_groups = nwin; }
+  else {
+    const int pack = 32 / wq;
+    if (nwin % pack) return sam2mi_set_error(ctx, "hiera_block_forward_generic", "window count not divisible by the packing factor");
+    a.GQ = 32; a.GK = pack * wk; a.num_groups = nwin / pack;
+  }
+  a.wq = wq; a.wk = wk;
+  const int Hq = b.q_pool ? H / 2 : H, Mq = B * Hq * Hq;
+  a.o = global ? ctx->ws_att16 : ctx->ws_o16; a.ldo = Co;
+  CHK(generic_attn_launch(a, hd, s));
+  if (!global) CHK(window_scatter_launch(ctx->ws_o16, ctx->ws_att16, B, Hq, Hq, Co, we, nW, wq, s));
+  {
+    GemmParams p = lin_params(ctx->ws_att16, Co, Mq, b.proj);
+    p.res = x; p.ldres = Co; p.out32 = x; p.ld32 = Co;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  if (b.q_pool) { H /= 2; W /= 2; }
+  CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s));
+  {
+    GemmParams p = lin_params(ctx->ws_a16, Co, Mq, b.fc1);
+    p.act = ACT_GELU; p.out16 = ctx->ws_h16; p.ld16 = 4 * Co;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  {
+    GemmParams p = lin_params(ctx->ws_h16, 4 * Co, Mq, b.fc2);
+    p.res = x; p.ldres = Co; p.out32 = x; p.ld32 = Co;
+    CHKI(run_gemm(ctx, s, p));
+  }
+  return 0;
+}
+
 // Runs patch embedding + all blocks; fills ctx->ws_lat[0..3] (neck laterals, window-major) and returns
 // the window size of each level's token order in wlev[].
 static int trunk_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, const uint8_t* img_u8, int B, int wlev[4]) {
@@ -151,8 +232,9 @@ static int trunk_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, const
   const int G = c.image_size / 4, E = c.embed_dim;
   int H = G, W = G, wcur = 8;
   // patch embed (conv 7x7 s4 p3 as im2col GEMM) + position table, written in window-major order
-  if (img_u8) CHK(im2col_patch_u8_launch(img_u8, B, c.image_size, ctx->ws_a16, s, ctx->lo16));
-  else CHK(im2col_patch_launch(img, B, c.image_size, ctx->ws_a16, s, ctx->lo16));
+  if (img_u8) CHK(im2col_patch_u8_launch(img_u8, B, c.image_size, ctx->ws_a16, s, ctx->lo16, ctx->generic));
+  else CHK(im2col_patch_launch(img, B, c.image_size, ctx->ws_a16, s, ctx->lo16, ctx->generic));
+  if (ctx->generic) wcur = G;                    // generic sizes: row-major tokens = one "window" as wide as the grid
   {
     GemmParams p = lin_params(ctx->ws_a16, 160, B * G * G, ctx->patch);
     p.res = ctx->pos_tab; p.ldres = E; p.res_mod = G * G;
@@ -162,9 +244,12 @@ static int trunk_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, const
   int level = 0;
   for (size_t i = 0; i < ctx->blocks.size(); ++i) {
     const HieraBlockW& b = ctx->blocks[i];
-    CHKI(hiera_block_forward(ctx, s, b, B, H, W, wcur));
+    if (ctx->generic) {
+      CHKI(hiera_block_forward_generic(ctx, s, b, B, H, W));
+      wcur = W;
+    } else CHKI(hiera_block_forward(ctx, s, b, B, H, W, wcur));
     // window size expected by the next block (hieradet.py:243-256: the window lags one block)
-    if (i + 1 < ctx->blocks.size()) {
+    if (!ctx->generic && i + 1 < ctx->blocks.size()) {
       const int wn = ctx->blocks[i + 1].window;
       if (wn > 0 && wn != wcur) {
         CHK(permute_tokens_launch(ctx->ws_x, ctx->ws_x2, B, H, W, b.dim_out, wcur, wn, nullptr, 0, s));

@@ -14,9 +14,9 @@ hipError_t cast_add_launch(const float* a, int lda, const float* b, int ldb, int
                            half_t* y16, int ldy16, float* y32, int ldy32, hipStream_t s, size_t lo_off = 0);
 // patch-embed im2col: img [B,3,S,S] f32 -> A [B*(S/4)^2, 160] f16, rows in window-major (w=8) token order,
 // column k = c*49 + ky*7 + kx (conv 7x7, stride 4, pad 3); columns 147..159 are zero.
-hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStream_t s, size_t lo_off = 0);
+hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStream_t s, size_t lo_off = 0, int row_major = 0);   // row_major: plain token order
 // same from decoded frames: uint8 [B, S, S, 3] HWC, normalised ((v/255 - mean)/std, ImageNet constants) on the fly
-hipError_t im2col_patch_u8_launch(const uint8_t* img_hwc, int B, int S, half_t* A, hipStream_t s, size_t lo_off = 0);
+hipError_t im2col_patch_u8_launch(const uint8_t* img_hwc, int B, int S, half_t* A, hipStream_t s, size_t lo_off = 0, int row_major = 0);
 // 2x2 max-pool inside w x w windows of window-major tokens: in [nwin*w*w, C] -> out [nwin*(w/2)^2, C]
 hipError_t pool_tokens_f32_launch(const float* in, int ldin, float* out, int ldout, int nwin, int w, int C, hipStream_t s);
 hipError_t pool_tokens_f16_launch(const half_t* in, int ldin, half_t* out, int ldout, int nwin, int w, int C, hipStream_t s);
@@ -32,6 +32,14 @@ hipError_t add_rowvec_launch(float* x, int ld, const float* v, int M, int C, con
 hipError_t round_bf16_launch(const float* in, float* out, size_t n, hipStream_t s);
 // fill f16 / f32
 hipError_t fill_f32_launch(float* p, float v, size_t n, hipStream_t s);
+
+// ---------------------------------------------------------------- hiera_generic.hip (window layouts of the padded-window model sizes)
+// src [B,H,W,C] f16 -> dst [B*nW*nW*wk, C]: window (wy,wx) owns wk rows, the first w*w are its tokens (zero outside the image), the rest zero
+hipError_t window_gather_launch(const half_t* src, half_t* dst, int B, int H, int W, int C, int w, int nW, int wk, hipStream_t s);
+// 2x2 max-pool of q inside every window: q [nwin*wk, ldq] -> out [nwin*wq, C], rows >= (w/2)^2 of a window zero
+hipError_t window_pool_q_launch(const half_t* q, int ldq, half_t* out, int C, int nwin, int w, int wk, int wq, hipStream_t s);
+// src [B*nW*nW*wq, C] (windows of edge `we`) -> dst [B,H,W,C], cropping the padding
+hipError_t window_scatter_launch(const half_t* src, half_t* dst, int B, int H, int W, int C, int we, int nW, int wq, hipStream_t s);
 
 // ---------------------------------------------------------------- convs.hip (memory encoder)
 // bilinear x4 upsample (align_corners=False) of low [256*256] + (binarize ? (x>0) : sigmoid(x)) * scale + bias -> out [1024*1024]

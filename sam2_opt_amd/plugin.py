@@ -45,17 +45,17 @@ class HipExecutor:
         pass                                   # the engine is shared; released by release_hip()
 
 
-def _check_hiera_large(sd):
-    """The HIP path implements the hiera-large trunk (window spec 8/4/16/8, no window padding).  Anything else must fail here,
-    at attach time, not as out-of-bounds device reads."""
-    from .config import get_config
-    cfg = get_config("large")
+def _detect_model(sd) -> str:
+    """Which SAM 2.1 size is this state_dict?  (embed_dim, number of Hiera blocks) identify it; anything else must fail here, at
+    attach time, not as out-of-bounds device reads."""
+    from .config import MODEL_CONFIGS
     w = sd.get("image_encoder.trunk.patch_embed.proj.weight")
     nblk = len({k.split(".")[3] for k in sd if k.startswith("image_encoder.trunk.blocks.")})
-    if w is None or w.shape[0] != cfg["embed_dim"] or nblk != sum(cfg["stages"]):
-        got = None if w is None else int(w.shape[0])
-        raise RuntimeError(f"speedup('hip') supports SAM 2.1 hiera-large only (embed_dim {cfg['embed_dim']}, {sum(cfg['stages'])} blocks); "
-                           f"this model has embed_dim {got}, {nblk} blocks")
+    for name, cfg in MODEL_CONFIGS.items():
+        if w is not None and int(w.shape[0]) == cfg["embed_dim"] and nblk == sum(cfg["stages"]):
+            return name
+    got = None if w is None else int(w.shape[0])
+    raise RuntimeError(f"speedup('hip'): not a SAM 2.1 hiera tiny / small / base+ / large model (embed_dim {got}, {nblk} blocks)")
 
 
 def _engine_for(model, precision: str = "f16", engine=None) -> Engine:
@@ -65,11 +65,11 @@ def _engine_for(model, precision: str = "f16", engine=None) -> Engine:
             eng = engine
         else:
             sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-            _check_hiera_large(sd)
+            size = _detect_model(sd)
             dev = next(model.parameters()).device
             if dev.type != "cuda":
                 raise RuntimeError("speedup('hip') needs the model on a ROCm GPU (model.to('cuda'))")
-            eng = Engine("large", state_dict=sd, max_batch=1, device=dev, precision=precision)
+            eng = Engine(size, state_dict=sd, max_batch=1, device=dev, precision=precision)
         model._sam2mi_engine = eng
     return eng
 

@@ -150,9 +150,16 @@ def test_image_predictor_surface():
     assert pred.set_image_e2e.__name__.endswith("_torch") and eng.closed
 
 
-def test_rejects_other_model_sizes():
+def test_model_size_detection():
     from sam2_opt_amd.config import get_config
-    from sam2_opt_amd.plugin import _check_hiera_large
-    from sam2_opt_amd.weights import synthetic_state_dict
-    with pytest.raises(RuntimeError, match="hiera-large only"):
-        _check_hiera_large(synthetic_state_dict(get_config("tiny"), seed=0))
+    from sam2_opt_amd.plugin import _detect_model
+    from sam2_opt_amd.weights import state_dict_spec
+    for name in ("tiny", "small", "base_plus", "large"):
+        sd = {k: torch.zeros(1).expand(*shape) if len(shape) else torch.zeros(()) for k, shape in state_dict_spec(get_config(name)).items()}
+        assert _detect_model(sd) == name
+    sd = dict(sd)
+    del sd["image_encoder.trunk.blocks.47.norm1.weight"], sd["image_encoder.trunk.blocks.47.norm1.bias"]
+    for k in [k for k in sd if k.startswith("image_encoder.trunk.blocks.47.")]:
+        del sd[k]
+    with pytest.raises(RuntimeError, match="not a SAM 2.1"):
+        _detect_model(sd)
