@@ -103,3 +103,24 @@ def test_tiny_image_predictor_config0():
     _check(gold, "tiny/ious", ious[0], atol=1e-5)
     _check(gold, "tiny/low_res", low[0], atol=1e-4)
     _check(gold, "tiny/masks_logits", masks[0], atol=1e-4)
+
+
+def test_oracle_encoder_small_and_base_plus():
+    """The padded-window sizes: the oracle's image encoder vs the REAL reference's (tests/golden/sizes_encoder.npz)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import sam2_ref as R
+    from oracle.golden_io import compare
+    from sam2_opt_amd.config import get_config
+    from sam2_opt_amd.synthetic import synthetic_image_normed
+    from sam2_opt_amd.weights import synthetic_state_dict
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sizes_encoder.npz"))
+    img = synthetic_image_normed(seed=1)
+    for name in ("small", "base_plus"):
+        cfg = get_config(name)
+        with torch.inference_mode():
+            outs = R.image_encoder(img, synthetic_state_dict(cfg, seed=0), cfg)
+        for k, n in ((0, "vision_features"), (4, "backbone_fpn0"), (5, "backbone_fpn1"), (6, "backbone_fpn2")):
+            ok, msg = compare(g, f"{name}/{n}", outs[k], atol=1e-4)
+            assert ok, msg
