@@ -31,8 +31,14 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // p.a_lo_off / p.w_lo_off elements behind the hi array.  A stage holds [A_hi | B_hi | A_lo | B_lo]; every fragment pair
 // costs three MFMAs: hi*hi into the main accumulator, lo*hi + hi*lo into a second one that is folded in (x 2^-11) before the
 // epilogue.  The dropped lo*lo term is 2^-22 relative; the 2^11 scale keeps the lo parts in the normal f16 range.
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT = false>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8 || SPLIT) ? 1 : 2) void gemm_v2_kernel(const GemmParams p) {
+// RS ("register-staged", K % 64 == 0, even piece split, 2 LDS stages): the K tiles do not arrive by LDS-DMA but through two
+// register sets - global -> VGPR loads issued TWO tiles ahead, written to the LDS stage (same lane-linear piece layout, so the
+// fragment reads are unchanged) one tile ahead.  Twice the bytes in flight of the 2-stage DMA ring at the same LDS footprint.
+// MEASURED AND LOST (tools/gemm_bench.py, hints 41-43): 10-20 % slower than the LDS-DMA ring on every K >= 576
+// shape (fc2 of stage 3: 132 us vs 111 us), equal at K = 144 - the extra VGPR -> LDS hop costs more than the deeper prefetch
+// buys, i.e. the loop is not short of bytes in flight.  Only compiled with -DSAM2MI_EXPERIMENTAL.
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT = false, bool RS = false>
+__global__ __launch_bounds__(WM * WN * 64, RS ? 4 : (WM * WN > 8 || SPLIT) ? 1 : 2) void gemm_v2_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -177,6 +183,61 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8 || SPLIT) ? 1 : 2) void 
     __builtin_amdgcn_s_barrier();
     if (kt + STAGES - 1 < nk) issue((kt + STAGES - 1) % STAGES, kt + STAGES - 1);
   };
+  if constexpr (RS) {
+    static_assert(EVEN && !SPLIT && STAGES == 2, "register staging: even piece split, plain operands, 2 LDS stages");
+    constexpr int NP = A_CALLS + B_CALLS;
+    f32x4 ra[NP], rb[NP];                                    // two register sets, used alternately (never indexed dynamically)
+    auto rs_load = [&](f32x4 (&r)[NP], int kt) {
+      const char* ka = baseA + (size_t)kt * 128;             // 64 halfs per K tile
+      const char* kb = baseB + (size_t)kt * 128;
+#pragma unroll
+      for (int j = 0; j < A_CALLS; ++j) r[j] = *reinterpret_cast<const f32x4*>(ka + a_off[j]);
+#pragma unroll
+      for (int j = 0; j < B_CALLS; ++j) r[A_CALLS + j] = *reinterpret_cast<const f32x4*>(kb + b_off[j]);
+    };
+    auto rs_commit = [&](const f32x4 (&r)[NP], int stage) {
+      char* sbase = smem + stage * STAGE + lane * 16;
+#pragma unroll
+      for (int j = 0; j < A_CALLS; ++j) *reinterpret_cast<f32x4*>(sbase + (wave * A_CALLS + j) * 1024) = r[j];
+#pragma unroll
+      for (int j = 0; j < B_CALLS; ++j) *reinterpret_cast<f32x4*>(sbase + A_BYTES + (wave * B_CALLS + j) * 1024) = r[A_CALLS + j];
+    };
+    auto compute = [&](int stage) {
+      const char* sA = smem + stage * STAGE;
+      const char* sB = sA + A_BYTES;
+      Frag f0 = ldfrag(sA, sB, 0);
+      Frag f1 = ldfrag(sA, sB, 1);
+      mma(f0);
+      f0 = ldfrag(sA, sB, 2);
+      mma(f1);
+      f1 = ldfrag(sA, sB, 3);
+      mma(f0);
+      mma(f1);
+    };
+    auto lds_barrier = [&]() {                               // LDS writes visible to the workgroup; the global loads stay in flight
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    rs_load(ra, 0);
+    if (nk > 1) rs_load(rb, 1);
+    rs_commit(ra, 0);
+    if (nk > 2) rs_load(ra, 2);
+    lds_barrier();
+#pragma nounroll
+    for (int kt = 0; kt < nk; kt += 2) {
+      // tile kt from stage 0; tile kt + 1 goes from register set B to stage 1 meanwhile, set B is re-armed with tile kt + 3
+      if (kt + 1 < nk) rs_commit(rb, 1);
+      if (kt + 3 < nk) rs_load(rb, kt + 3);
+      compute(0);
+      lds_barrier();
+      if (kt + 1 < nk) {
+        if (kt + 2 < nk) rs_commit(ra, 0);
+        if (kt + 4 < nk) rs_load(ra, kt + 4);
+        compute(1);
+        lds_barrier();
+      }
+    }
+  } else {
 #pragma unroll
   for (int st = 0; st < STAGES - 1; ++st)
     if (st < nk) issue(st, st);
@@ -209,6 +270,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8 || SPLIT) ? 1 : 2) void 
       mma(f);
     }
   }
+  }
   if constexpr (SPLIT) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -221,7 +283,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8 || SPLIT) ? 1 : 2) void 
 
   // ------------------------------------------------------------------ epilogue
   float* patch = reinterpret_cast<float*>(smem) + wave * 1024;     // wave-private 32x32 f32
+  // RoPE (host contract, gemm_v2_launch): rope_cols <= n_split, rope_cols % 4 == 0, rope_dim % 4 == 0, N % 4 == 0
   const bool has_rope = p.rope_cols > 0;
+  const bool rope_pow2 = (p.rope_len & (p.rope_len - 1)) == 0;
+  int rope_pr[TN];                                                  // pair index of the lane's first column in phase 2
+#pragma unroll
+  for (int j = 0; j < TN; ++j) rope_pr[j] = has_rope ? ((n0 + wn * WTN + j * 32 + (lane & 7) * 4) % p.rope_dim) >> 1 : 0;
   const bool vec_ok = (p.N & 3) == 0 && (p.ld32 & 3) == 0 && (p.ld16 & 3) == 0 && (p.ldres & 3) == 0;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -241,19 +308,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8 || SPLIT) ? 1 : 2) void 
       for (int r = 0; r < 16; ++r) {
         const int m = mt0 + acc_row(r, lane);
         float x = acc[i][j][r] + bias;
-        if (has_rope) {
-          const float partner = __shfl_xor(x, 1, 64);
-          if (n < p.rope_cols && m < p.rope_rows) {
-            const int pr = (n % p.rope_dim) >> 1;
-            const size_t ti = (size_t)(m % p.rope_len) * (p.rope_dim >> 1) + pr;
-            const float c = p.rope_cos[ti], sn = p.rope_sin[ti];
-            x = (n & 1) ? (partner * sn + x * c) : (x * c - partner * sn);
-          }
-        }
         if (p.act == ACT_GELU) x = gelu_erf_fast(x);
         else if (p.act == ACT_RELU) x = fmaxf(x, 0.f);
         else if (p.act == ACT_SIGMOID) x = 1.f / (1.f + __expf(-x));
-        v[r] = x * cscale;
+        v[r] = has_rope ? x : x * cscale;             // RoPE: rotated in phase 2, the column scale follows the rotation
       }
       if (transposed) {
         const int nt = n - p.n_split;
@@ -301,6 +359,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8 || SPLIT) ? 1 : 2) void 
         const int m = mt0 + rr, nn = nt0 + c4;
         if (m < p.M && nn < p.N) {
           float o[4] = {t[0], t[1], t[2], t[3]};
+          if (has_rope) {                                           // a lane holds the pairs (nn, nn+1), (nn+2, nn+3) of row m
+            if (nn < p.rope_cols && m < p.rope_rows) {
+              const int tr = rope_pow2 ? (m & (p.rope_len - 1)) : (m % p.rope_len);
+              const size_t ti = (size_t)tr * (p.rope_dim >> 1) + rope_pr[j];
+              const float2 c = *reinterpret_cast<const float2*>(p.rope_cos + ti), sn = *reinterpret_cast<const float2*>(p.rope_sin + ti);
+              const float a0 = o[0], a1 = o[1], a2 = o[2], a3 = o[3];
+              o[0] = a0 * c.x - a1 * sn.x; o[1] = a0 * sn.x + a1 * c.x;
+              o[2] = a2 * c.y - a3 * sn.y; o[3] = a2 * sn.y + a3 * c.y;
+            }
+            if (p.col_scale) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (nn + e < p.N) o[e] *= p.col_scale[nn + e];
+            }
+          }
           const size_t rrow = (size_t)(p.res_mod ? m % p.res_mod : m);
           if (vec_ok) {                                             // N % 4 == 0: the 4 columns are all valid
             if (p.res) {
@@ -337,16 +410,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN > 8 || SPLIT) ? 1 : 2) void 
 template <int BM, int BN, int STAGES, bool SPLIT = false>
 constexpr size_t v2_smem() { return (size_t)STAGES * (BM + BN) * 128 * (SPLIT ? 2 : 1); }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT = false, bool RS = false>
 hipError_t v2_launch(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const size_t smem = v2_smem<BM, BN, STAGES, SPLIT>();
-  gemm_v2_kernel<BM, BN, WM, WN, STAGES, SPLIT><<<dim3(tiles), dim3(WM * WN * 64), smem, s>>>(p);
+  gemm_v2_kernel<BM, BN, WM, WN, STAGES, SPLIT, RS><<<dim3(tiles), dim3(WM * WN * 64), smem, s>>>(p);
   return hipGetLastError();
 }
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT = false>
+template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT = false, bool RS = false>
 hipError_t v2_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v2_kernel<BM, BN, WM, WN, STAGES, SPLIT>),
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v2_kernel<BM, BN, WM, WN, STAGES, SPLIT, RS>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_smem<BM, BN, STAGES, SPLIT>());
 }
 }  // namespace
@@ -356,6 +429,7 @@ hipError_t gemm_v2_init() {
       v2_attr<128, 192, 4, 2, 2>(), v2_attr<128, 128, 4, 2, 2>(), v2_attr<128, 64, 4, 2, 2>(), v2_attr<64, 64, 2, 2, 2>(),
       v2_attr<128, 128, 4, 2, 2, true>(), v2_attr<128, 64, 4, 2, 2, true>(), v2_attr<64, 64, 2, 2, 2, true>(),
 #ifdef SAM2MI_EXPERIMENTAL
+      v2_attr<128, 192, 4, 2, 2, false, true>(), v2_attr<128, 128, 4, 2, 2, false, true>(), v2_attr<128, 64, 4, 2, 2, false, true>(),
       v2_attr<256, 192, 4, 2, 2>(), v2_attr<256, 256, 4, 4, 2>(), v2_attr<256, 192, 4, 3, 2>(), v2_attr<256, 128, 4, 2, 3>(), v2_attr<128, 128, 2, 2, 2>(),
       v2_attr<128, 64, 2, 2, 2>(), v2_attr<128, 64, 2, 2, 3>(), v2_attr<128, 128, 2, 2, 3>(), v2_attr<64, 64, 2, 2, 4>(), v2_attr<256, 128, 4, 2, 2>(),
       v2_attr<256, 64, 4, 2, 2>(),
@@ -377,6 +451,9 @@ static inline long tiles_of(const GemmParams& p, int bm, int bn) { return (long)
 // schedule, not more bytes per barrier).  The loop is bound by the per-CU L2->LDS rate (~25-29 B/clk) at these tiles.
 // The losing tiles are only compiled with -DSAM2MI_EXPERIMENTAL (tile_hint, tools/gemm_bench.py).
 hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
+  if (p.rope_cols > 0 && (p.rope_cols > p.n_split || (p.rope_cols & 3) || (p.rope_dim & 3) || (p.N & 3) || (p.ld32 & 3) || (p.ld16 & 3) ||
+                          (p.ldres & 3) || p.rope_len <= 0))
+    return hipErrorInvalidValue;                          // RoPE runs on the row-major 4-column phase of the epilogue
   if (p.a_lo_off || p.w_lo_off) {                        // split-f16 operands (f16x3 precision mode)
     if (!p.a_lo_off || !p.w_lo_off) return hipErrorInvalidValue;
     switch (gemm_v2_auto_tile(p)) {
@@ -401,6 +478,12 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   if (force == 14) return v2_launch<256, 256, 4, 4, 2>(p, s);
   if (force == 15) return v2_launch<256, 192, 4, 3, 2>(p, s);
   if (force == 4) return v2_launch<128, 64, 2, 2, 2>(p, s);
+  // register-staged variants (hints 41..43): K % 64 == 0 only
+  if (force >= 41 && force <= 43 && (p.K & 63) == 0) {
+    if (force == 43) return v2_launch<128, 192, 4, 2, 2, false, true>(p, s);
+    if (force == 42) return v2_launch<128, 128, 4, 2, 2, false, true>(p, s);
+    return v2_launch<128, 64, 4, 2, 2, false, true>(p, s);
+  }
 #endif
   int tile = gemm_v2_auto_tile(p);
   switch (p.tile_hint) {                                 // the four production tiles can be forced (benchmarks, parity tests)
