@@ -426,12 +426,12 @@ hipError_t v2_attr() {
 
 hipError_t gemm_v2_init() {
   const hipError_t e[] = {
-      v2_attr<128, 192, 4, 2, 2>(), v2_attr<128, 128, 4, 2, 2>(), v2_attr<128, 64, 4, 2, 2>(), v2_attr<64, 64, 2, 2, 2>(),
+      v2_attr<128, 192, 4, 2, 2>(), v2_attr<128, 128, 4, 2, 2>(), v2_attr<128, 64, 4, 2, 2>(), v2_attr<64, 64, 2, 2, 2>(), v2_attr<64, 64, 2, 2, 4>(),
       v2_attr<128, 128, 4, 2, 2, true>(), v2_attr<128, 64, 4, 2, 2, true>(), v2_attr<64, 64, 2, 2, 2, true>(),
 #ifdef SAM2MI_EXPERIMENTAL
       v2_attr<128, 192, 4, 2, 2, false, true>(), v2_attr<128, 128, 4, 2, 2, false, true>(), v2_attr<128, 64, 4, 2, 2, false, true>(),
       v2_attr<256, 192, 4, 2, 2>(), v2_attr<256, 256, 4, 4, 2>(), v2_attr<256, 192, 4, 3, 2>(), v2_attr<256, 128, 4, 2, 3>(), v2_attr<128, 128, 2, 2, 2>(),
-      v2_attr<128, 64, 2, 2, 2>(), v2_attr<128, 64, 2, 2, 3>(), v2_attr<128, 128, 2, 2, 3>(), v2_attr<64, 64, 2, 2, 4>(), v2_attr<256, 128, 4, 2, 2>(),
+      v2_attr<128, 64, 2, 2, 2>(), v2_attr<128, 64, 2, 2, 3>(), v2_attr<128, 128, 2, 2, 3>(), v2_attr<256, 128, 4, 2, 2>(),
       v2_attr<256, 64, 4, 2, 2>(),
 #endif
   };
@@ -471,7 +471,6 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   if (force == 3) return v2_launch<128, 128, 2, 2, 2>(p, s);
   if (force == 7) return v2_launch<128, 64, 2, 2, 3>(p, s);
   if (force == 8) return v2_launch<128, 128, 2, 2, 3>(p, s);
-  if (force == 9) return v2_launch<64, 64, 2, 2, 4>(p, s);
   if (force == 11) return v2_launch<256, 128, 4, 2, 2>(p, s);
   if (force == 12) return v2_launch<256, 64, 4, 2, 2>(p, s);
   if (force == 17) return v2_launch<256, 192, 4, 2, 2>(p, s);
@@ -491,17 +490,19 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
     case 10: tile = 2; break;
     case 13: tile = 1; break;
     case 5: tile = 0; break;
+    case 9: tile = 4; break;
     default: break;
   }
   switch (tile) {
     case 3: return v2_launch<128, 192, 4, 2, 2>(p, s);
     case 2: return v2_launch<128, 128, 4, 2, 2>(p, s);
     case 1: return v2_launch<128, 64, 4, 2, 2>(p, s);
+    case 4: return v2_launch<64, 64, 2, 2, 4>(p, s);
     default: return v2_launch<64, 64, 2, 2, 2>(p, s);
   }
 }
 
-// automatic tile: 3 = 128x192, 2 = 128x128, 1 = 128x64 (8 waves), 0 = 64x64 (4 waves)
+// automatic tile: 3 = 128x192, 2 = 128x128, 1 = 128x64 (8 waves), 0 = 64x64 (4 waves), 4 = 64x64 with a 4-stage ring
 int gemm_v2_auto_tile(const GemmParams& p) {
   // long K, N a multiple of 192 (fc2 of stages 3-4: N = 576 / 1152): the 128x192 tile re-reads the A panel N/192 instead of
   // N/64 times through the L2->LDS path that bounds this kernel (measured +14 % / +16 % on those two shapes)
@@ -511,15 +512,22 @@ int gemm_v2_auto_tile(const GemmParams& p) {
   const bool fits128 = (n128 - p.N) * 100 <= 8 * p.N;              // N pads to 128 with at most 8 % waste
   if (fits128 && (t128 >= 1536 || (t128 >= 512 && p.K >= 2048))) return 2;
   if (tiles_of(p, 128, 64) >= 1024) return 1;
+  // small grids (the M = 4096 GEMMs of the tracking path) run ~1 workgroup per CU with operands that the previous kernel has just
+  // written, i.e. served by the memory-side cache, not by the XCD's L2: with one K tile in flight the loop is latency-bound
+  // (ff2 of the memory attention, K = 2048: 26.6 us in the pipeline vs 13.9 us on L2-hot operands in tools/gemm_bench.py).  A
+  // 4-stage ring (3 tiles in flight) takes it to 16 us in the pipeline; no effect on L2-hot operands.
+  if (p.K >= 512) return 4;
   return 0;
 }
 
 // kernel name as rocprofv3 prints it (profiling by instantiation)
 const char* gemm_v2_kernel_name(const GemmParams& p) {
   if (p.tile_hint != 0) return "gemm_v2_kernel<forced tile>";
-  static const char* names[4] = {"gemm_v2_kernel<64, 64, 2, 2, 2, false>", "gemm_v2_kernel<128, 64, 4, 2, 2, false>", "gemm_v2_kernel<128, 128, 4, 2, 2, false>",
-                                 "gemm_v2_kernel<128, 192, 4, 2, 2, false>"};
-  static const char* split_names[4] = {"gemm_v2_kernel<64, 64, 2, 2, 2, true>", "gemm_v2_kernel<128, 64, 4, 2, 2, true>", "gemm_v2_kernel<128, 128, 4, 2, 2, true>",
-                                       "gemm_v2_kernel<128, 128, 4, 2, 2, true>"};
+  static const char* names[5] = {"gemm_v2_kernel<64, 64, 2, 2, 2, false, false>", "gemm_v2_kernel<128, 64, 4, 2, 2, false, false>",
+                                 "gemm_v2_kernel<128, 128, 4, 2, 2, false, false>", "gemm_v2_kernel<128, 192, 4, 2, 2, false, false>",
+                                 "gemm_v2_kernel<64, 64, 2, 2, 4, false, false>"};
+  static const char* split_names[5] = {"gemm_v2_kernel<64, 64, 2, 2, 2, true, false>", "gemm_v2_kernel<128, 64, 4, 2, 2, true, false>",
+                                       "gemm_v2_kernel<128, 128, 4, 2, 2, true, false>", "gemm_v2_kernel<128, 128, 4, 2, 2, true, false>",
+                                       "gemm_v2_kernel<64, 64, 2, 2, 2, true, false>"};
   return (p.a_lo_off ? split_names : names)[gemm_v2_auto_tile(p)];
 }

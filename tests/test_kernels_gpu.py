@@ -28,7 +28,7 @@ def r16(x):
     (300, 200, 144, 0, False), (4096, 1728, 576, 0, False), (16384, 432, 144, 1, True), (8, 256, 256, 2, False),
     (1000, 64, 160, 0, True), (4096, 4, 32, 0, False), (129, 65, 2304, 1, True), (4096, 576, 2304, 0, True),
 ])
-@pytest.mark.parametrize("hint", [0, 5, 10, 13, 16])   # automatic, then the four production tiles forced: 64x64, 128x128, 128x64, 128x192
+@pytest.mark.parametrize("hint", [0, 5, 9, 10, 13, 16])   # automatic, then the production tiles forced: 64x64, 64x64 4-stage, 128x128, 128x64, 128x192
 def test_gemm(eng, M, N, K, act, res, hint):
     g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
     A = r16(torch.randn(M, K, generator=g)).cuda()
