@@ -52,7 +52,8 @@ struct Flash256Params {
   int splits;                   // KV splits (grid.y)
   float* o_part;                // [splits, Nq, 256] f32 un-normalised partial outputs
   float* ml_part;               // [splits, Nq, 2] f32 (running max in log2 domain, running sum)
-  half_t* out; int ldout;       // [Nq, ldout] f16 final (written by the combine pass)
+  half_t* out; int ldout;       // [Nq, ldout] f16 final (written by the combine pass); nullptr: no combine pass, the consumer
+                                //   combines the partials itself (gemm_rowln.hip)
   float scale_log2e;            // unused by the kernel (q is pre-scaled); kept for the debug entry point
   size_t out_lo_off;            // split-f16 mode: `out` is written as hi + lo (common.h); 0: off
 };

@@ -499,7 +499,7 @@ hipError_t flash256_launch(const Flash256Params& p, hipStream_t stream) {
     else flash256_v3_kernel<0, false, 4><<<grid, block, lds, stream>>>(p);
   }
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess || !p.out) return e;
   flash256_combine_kernel<<<dim3(p.Nq / 4), dim3(256), 0, stream>>>(p);
   return hipGetLastError();
 }

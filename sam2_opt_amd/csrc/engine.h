@@ -241,6 +241,7 @@ struct sam2mi_ctx {
   bool use_ks = false;             // accumulator-stationary GEMM for stage-3 fc2 (experimental, SAM2MI_KS=1; parity-tested, not faster end to end)
   bool use_xs = true;              // X-stationary GEMM for K <= 576 linears of the encoder (SAM2MI_NO_XS=1: tiled kernel)
   bool ln_fuse = false;            // LN1 / LN2 of Hiera blocks computed inside the consumer's operand load (opt-in: SAM2MI_LN_FUSE=1; no end-to-end gain)
+  bool use_rowln = true;           // memory attention: combine + out-projection + residual + next LayerNorm in one kernel (SAM2MI_NO_ROWLN=1: three kernels)
   bool use_fused_mlp = true;       // stages with C <= 288: one fused fc1-GELU-fc2 kernel (SAM2MI_NO_FUSED_MLP=1: two GEMMs, for A/B runs)
 };
 
@@ -259,6 +260,7 @@ int sam2mi_set_error(sam2mi_ctx* ctx, const char* what, const char* detail);
 // engine_core.hip
 void* dalloc(sam2mi_ctx* ctx, size_t bytes);
 int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p);                 // with profiling
+int run_rowln(sam2mi_ctx* ctx, hipStream_t s, const RowLnParams& p);               // gemm_rowln.hip, with profiling
 bool xs_eligible(const sam2mi_ctx* ctx, const GemmParams& p);                      // will run_gemm take the X-stationary kernel?
 int run_hiera_attn(sam2mi_ctx* ctx, hipStream_t s, const HieraAttnParams& p);
 int run_mlp_fused(sam2mi_ctx* ctx, hipStream_t s, const MlpFusedParams& p, int C);     // with profiling

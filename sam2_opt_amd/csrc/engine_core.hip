@@ -169,6 +169,16 @@ int run_precise_attn(sam2mi_ctx* ctx, hipStream_t s, const PreciseAttnParams& p)
   if (ctx->prof_on) prof_end(ctx->prof_attn, s, e0, e1, 4.0 * p.num_groups * (double)p.GQ * nk_vis * 72.0 * p.heads);
   return 0;
 }
+int run_rowln(sam2mi_ctx* ctx, hipStream_t s, const RowLnParams& p) {
+  hipEvent_t e0, e1;
+  if (ctx->prof_on) prof_begin(ctx, ctx->prof_gemm, s, e0, e1);
+  CHK(gemm_rowln_launch(p, s));
+  // algorithmic bytes: partials (or the f16 operand) + weights + residual in and out + f16 LayerNorm output
+  const double bytes = (p.o_part ? (double)p.splits * p.M * (256.0 * 4 + 8) : p.M * 512.0) + 256.0 * 512 + p.M * 256.0 * (4 + 4 + 2);
+  if (ctx->prof_on) prof_end_named(ctx, ctx->prof_gemm, "gemm_rowln_kernel", s, e0, e1, 2.0 * p.M * 256.0 * 256.0, bytes);
+  return 0;
+}
+
 int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p) {
   hipEvent_t e0, e1;
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_attn, s, e0, e1);
@@ -344,6 +354,7 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   // on the split-operand instantiation of the tiled kernel (gemm2.hip)
   ctx->use_fused_mlp = !ctx->precise && getenv("SAM2MI_NO_FUSED_MLP") == nullptr;
   ctx->use_xs = !ctx->precise && getenv("SAM2MI_NO_XS") == nullptr;
+  ctx->use_rowln = !ctx->precise && getenv("SAM2MI_NO_ROWLN") == nullptr;
   // LayerNorm inside the operand load of the X-stationary / fused-MLP kernels: parity-tested, but measured EQUAL end to end
   // (205.6 vs 205.7 frames/s): the row is read twice as f32 by every column split, which costs what the separate LayerNorm
   // kernel cost (it runs at 5.5 TB/s) and moves more bytes past the L2.  Opt-in for A/B runs.

@@ -152,6 +152,30 @@ extern "C" int sam2mi_debug_flash256(sam2mi_ctx* ctx, void* stream, const float*
   return 0;
 }
 
+// gemm_rowln_kernel on its own: partials [splits, M, 256] + ml [splits, M, 2] (or, splits == 0, a plain operand a [M, 256] f32 that is
+// rounded to f16), W [256, 256] f32, bias, residual x [M, 256] (updated in place), LayerNorm weights -> h [M, 256] f32 (from f16)
+extern "C" int sam2mi_debug_rowln(sam2mi_ctx* ctx, void* stream, const float* a_or_parts, const float* ml, int splits, const float* W,
+                                  const float* bias, float* x, const float* ln_w, const float* ln_b, int M, float* h) {
+  if (!ctx) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  Tmp t;
+  half_t* w16 = t.get<half_t>(256 * 256);
+  half_t* a16 = t.get<half_t>((size_t)M * 256);
+  half_t* h16 = t.get<half_t>((size_t)M * 256);
+  if (!w16 || !a16 || !h16) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+  CHK(cast_add_launch(W, 256, nullptr, 0, 0, 0.f, 256, 256, w16, 256, nullptr, 0, s));
+  RowLnParams r;
+  memset(&r, 0, sizeof(r));
+  if (splits > 0) { r.o_part = a_or_parts; r.ml_part = ml; r.splits = splits; r.part_rows = M; }
+  else { CHK(cast_add_launch(a_or_parts, 256, nullptr, 0, 0, 0.f, M, 256, a16, 256, nullptr, 0, s)); r.a16 = a16; r.lda = 256; }
+  r.w = w16; r.bias = bias; r.res = x; r.out32 = x; r.ln_w = ln_w; r.ln_b = ln_b; r.eps = 1e-5f; r.out16 = h16; r.ld16 = 256; r.M = M;
+  CHKI(run_rowln(ctx, s, r));
+  f16_to_f32_kernel<<<dim3((unsigned)(((size_t)M * 256 + 255) / 256)), dim3(256), 0, s>>>(h16, h, (size_t)M * 256);
+  CHK(hipGetLastError());
+  CHK(hipStreamSynchronize(s));
+  return 0;
+}
+
 // One Hiera block on x [B, H, W, C] (row-major NHWC, H = W = the grid of that block's stage) -> out NHWC
 extern "C" int sam2mi_debug_hiera_block(sam2mi_ctx* ctx, void* stream, int block_idx, const float* x_nhwc, int B, float* out_nhwc) {
   if (!ctx || !ctx->finalized) return sam2mi_set_error(ctx, __func__, "weights not finalized");

@@ -33,6 +33,16 @@ static int dummy_launches(sam2mi_ctx* ctx, hipStream_t s) {
 // object (each object has its own memory bank).  Inputs: curr / curr_pos [4096,256] f32 (shared by the objects);
 // ctx->t_kin16 / t_vin16 + n * t_nk_cap * 64 hold f16(memory+pos) / f16(memory) of object n: Nk[n] keys of which the first
 // n_rope[n] get RoPE.  Output [N,4096,256] f32.
+// combine(flash partials) -> out-projection + residual -> LayerNorm of the next sub-block, one launch (gemm_rowln.hip)
+static int attn_tail(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& f, const Lin16& out_proj, const Norm& ln, float* x, half_t* h16) {
+  RowLnParams r;
+  memset(&r, 0, sizeof(r));
+  r.o_part = f.o_part; r.ml_part = f.ml_part; r.splits = f.splits; r.part_rows = f.Nq;
+  r.w = out_proj.w; r.bias = out_proj.b; r.res = x; r.out32 = x; r.ln_w = ln.w; r.ln_b = ln.b; r.eps = 1e-5f; r.out16 = h16; r.ld16 = 256; r.M = f.Nq;
+  if (out_proj.N != 256 || out_proj.K != 256) return sam2mi_set_error(ctx, "attn_tail", "out-projection is not 256 x 256");
+  return run_rowln(ctx, s, r);
+}
+
 int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const float* curr_pos, int N, const int* Nk, const int* n_rope,
                     float* out32) {
   const int S = 4096, C = 256;
@@ -40,6 +50,7 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
   const int M = N * S;
   const size_t cap = (size_t)ctx->t_nk_cap;
   float* x = ctx->t_x;
+  const bool fused_tail = ctx->use_rowln;      // f16x3: split operands, the three-kernel tail
   for (int n = 0; n < N; ++n) {
     if (Nk[n] <= 0 || ceil32(Nk[n]) > ctx->t_nk_cap) return sam2mi_set_error(ctx, "memattn_forward", "memory length out of range");
     // x = curr + 0.1 * curr_pos   (pos_enc_at_input, :319-321)
@@ -69,16 +80,18 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
       memset(&f, 0, sizeof(f));
       f.q = ctx->t_qk16 + (size_t)n * S * 512; f.ldq = 512; f.k = f.q + 256; f.ldk = 512; f.vT = ctx->t_vT16 + (size_t)n * S; f.ldvT = M;
       f.Nq = S; f.Nk = S; f.splits = flash256_pick_splits(S, S); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
-      f.out = ctx->t_o16 + (size_t)n * S * C; f.ldout = C; f.scale_log2e = LOG2E / 16.f; f.out_lo_off = ctx->lo16;
+      f.out = fused_tail ? nullptr : ctx->t_o16 + (size_t)n * S * C; f.ldout = C; f.scale_log2e = LOG2E / 16.f; f.out_lo_off = ctx->lo16;
       CHKI(run_flash256(ctx, s, f));
+      // x += out_proj(attention), h = norm2(x): with the combine of the flash partials in one kernel (gemm_rowln.hip)
+      if (fused_tail) CHKI(attn_tail(ctx, s, f, L.self_out, L.n2, x + (size_t)n * S * C, ctx->t_h16 + (size_t)n * S * C));
     }
-    {
+    if (!fused_tail) {
       GemmParams p = lin_params(ctx->t_o16, C, M, L.self_out);
       p.res = x; p.ldres = C; p.out32 = x; p.ld32 = C;
       CHKI(run_gemm(ctx, s, p));
+      // ---- cross attention to the memory bank
+      CHK(layernorm_launch(x, C, L.n2.w, L.n2.b, 1e-5f, M, C, ctx->t_h16, C, nullptr, 0, 0, s, ctx->lo16));
     }
-    // ---- cross attention to the memory bank
-    CHK(layernorm_launch(x, C, L.n2.w, L.n2.b, 1e-5f, M, C, ctx->t_h16, C, nullptr, 0, 0, s, ctx->lo16));
     {
       GemmParams p = lin_params(ctx->t_h16, C, M, L.cross_q);
       p.out16 = ctx->t_q16; p.ld16 = C; p.col_scale = ctx->qs_cross;
@@ -92,16 +105,17 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
       f.q = ctx->t_q16 + (size_t)n * S * C; f.ldq = C; f.k = ctx->t_kall16 + n * cap * 1024 + l * 256; f.ldk = 1024;
       f.vT = ctx->t_vTall16 + n * cap * 1024 + (size_t)l * 256 * NkP; f.ldvT = NkP;
       f.Nq = S; f.Nk = Nk[n]; f.splits = flash256_pick_splits(S, Nk[n]); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
-      f.out = ctx->t_o16 + (size_t)n * S * C; f.ldout = C; f.scale_log2e = LOG2E / 16.f; f.out_lo_off = ctx->lo16;
+      f.out = fused_tail ? nullptr : ctx->t_o16 + (size_t)n * S * C; f.ldout = C; f.scale_log2e = LOG2E / 16.f; f.out_lo_off = ctx->lo16;
       CHKI(run_flash256(ctx, s, f));
+      if (fused_tail) CHKI(attn_tail(ctx, s, f, L.cross_out, L.n3, x + (size_t)n * S * C, ctx->t_h16 + (size_t)n * S * C));
     }
-    {
+    if (!fused_tail) {
       GemmParams p = lin_params(ctx->t_o16, C, M, L.cross_out);
       p.res = x; p.ldres = C; p.out32 = x; p.ld32 = C;
       CHKI(run_gemm(ctx, s, p));
+      // ---- FFN
+      CHK(layernorm_launch(x, C, L.n3.w, L.n3.b, 1e-5f, M, C, ctx->t_h16, C, nullptr, 0, 0, s, ctx->lo16));
     }
-    // ---- FFN
-    CHK(layernorm_launch(x, C, L.n3.w, L.n3.b, 1e-5f, M, C, ctx->t_h16, C, nullptr, 0, 0, s, ctx->lo16));
     {
       GemmParams p = lin_params(ctx->t_h16, C, M, L.lin1);
       p.act = ACT_RELU; p.out16 = ctx->t_ff16; p.ld16 = 2048;

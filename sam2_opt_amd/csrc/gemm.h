@@ -51,6 +51,19 @@ hipError_t gemm_v2_init();
 int gemm_v2_auto_tile(const GemmParams& p);              // the tile the automatic choice takes (0: 64x64 .. 3: 128x192)
 const char* gemm_v2_kernel_name(const GemmParams& p);    // kernel name as rocprofv3 prints it
 // gemm3.hip: persistent loader/consumer kernel (large M*N, K % 16 == 0)
+// ---- out-projection + residual + LayerNorm of a d_model = 256 attention sub-block in one kernel (gemm_rowln.hip)
+struct RowLnParams {
+  const half_t* a16; int lda;        // operand [M, 256] f16 ...
+  const float* o_part; const float* ml_part; int splits; int part_rows;   // ... or (o_part != nullptr) the flash256 partials to combine:
+                                     //     o_part [splits, part_rows, 256] f32, ml_part [splits, part_rows, 2] f32 (attn.h, Flash256Params)
+  const half_t* w; const float* bias;   // W [256, 256] f16 row-major (out, in), bias [256] or nullptr
+  const float* res; float* out32;    // out32 = res + operand W^T + bias   [M, 256] f32 (may alias)
+  const float* ln_w; const float* ln_b; float eps;
+  half_t* out16; int ld16;           // LayerNorm(out32) * ln_w + ln_b as f16
+  int M;                             // multiple of 32
+};
+hipError_t gemm_rowln_launch(const RowLnParams& p, hipStream_t stream);
+
 hipError_t gemm_v3_launch(const GemmParams& p, hipStream_t stream);
 hipError_t gemm_v3_init();
 // gemm4.hip: 256x256 staggered 4-phase kernel, one workgroup per CU (experimental; K % 64 == 0)

@@ -20,7 +20,7 @@ EXPORTS = [
     "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_prompt_encoder_ex", "sam2mi_dense_pe", "sam2mi_video_encode", "sam2mi_video_encode_u8", "sam2mi_fill_holes", "sam2mi_set_fill_hole_area",
     "sam2mi_video_click", "sam2mi_video_mask", "sam2mi_image_predict", "sam2mi_image_predict_ex", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_video_track_batch", "sam2mi_resize_bilinear",
     "sam2mi_resize_u8_pil_bicubic", "sam2mi_resize_image_aa_bilinear", "sam2mi_stream_create_reserved", "sam2mi_stream_destroy", "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_profile_read_mlp", "sam2mi_profile_read_xs", "sam2mi_profile_read_ks", "sam2mi_profile_read_kernels", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
-    "sam2mi_debug_flash256", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench", "sam2mi_debug_mlp",
+    "sam2mi_debug_flash256", "sam2mi_debug_rowln", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench", "sam2mi_debug_mlp",
 ]
 
 
@@ -451,6 +451,18 @@ class Engine:
         self._check(self.lib.sam2mi_debug_flash256(self.h, self.stream, _ptr(q.contiguous()), _ptr(k.contiguous()),
                                                    _ptr(v.contiguous()), q.shape[0], k.shape[0], _ptr(out)), "sam2mi_debug_flash256")
         return out
+
+    def debug_rowln(self, a, ml, W, bias, x, ln_w, ln_b):
+        """gemm_rowln_kernel: a = flash partials (splits, M, 256) with ml (splits, M, 2), or a plain (M, 256) operand with ml None.
+        Returns (x + a' W^T + bias, LayerNorm of that as the f16 values)."""
+        splits = a.shape[0] if ml is not None else 0
+        M = x.shape[0]
+        x = x.clone().contiguous()
+        h = self.new(M, 256)
+        self._check(self.lib.sam2mi_debug_rowln(self.h, self.stream, _ptr(a.contiguous()), _ptr(ml.contiguous()) if ml is not None else None, splits,
+                                                _ptr(W.contiguous()), _ptr(bias.contiguous()), _ptr(x), _ptr(ln_w.contiguous()), _ptr(ln_b.contiguous()),
+                                                M, _ptr(h)), "sam2mi_debug_rowln")
+        return x, h
 
     def debug_hiera_block(self, idx: int, x_nhwc: torch.Tensor, out_shape):
         out = self.new(*out_shape)

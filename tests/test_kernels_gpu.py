@@ -154,6 +154,30 @@ def test_gemm_ks(eng, M, K, res):
     check(f"gemm_ks {M}x{N}x{K}", out, ref.float(), 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("splits", [0, 1, 8])
+def test_rowln_fused_attention_tail(eng, splits):
+    """gemm_rowln_kernel (combine of the flash partials + out-projection + residual + LayerNorm) against torch in f64."""
+    g = torch.Generator(device="cpu").manual_seed(11 + splits)
+    M = 4096
+    W = r16(torch.randn(256, 256, generator=g) / 16).cuda()
+    b, x = torch.randn(256, generator=g).cuda(), torch.randn(M, 256, generator=g).cuda()
+    lw, lb = (1 + 0.1 * torch.randn(256, generator=g)).cuda(), (0.1 * torch.randn(256, generator=g)).cuda()
+    if splits == 0:
+        a, ml = r16(torch.randn(M, 256, generator=g)).cuda(), None
+        o = a.double()
+    else:
+        a = torch.randn(splits, M, 256, generator=g).cuda() * 3
+        ml = torch.stack([torch.randn(splits, M, generator=g) * 4, torch.rand(splits, M, generator=g) * 5 + 0.5], dim=-1).cuda()
+        w = torch.exp2(ml[..., 0].double() - ml[..., 0].double().max(dim=0, keepdim=True).values)            # (splits, M)
+        o = (w[..., None] * a.double()).sum(0) / (w * ml[..., 1].double()).sum(0)[..., None]
+        o = o.float().half().double()                                                                     # the kernel's f16 operand
+    x_ref = x.double() + o @ W.double().t() + b.double()
+    h_ref = F.layer_norm(x_ref, (256,), lw.double(), lb.double(), 1e-5)
+    x_out, h_out = eng.debug_rowln(a, ml, W, b, x, lw, lb)
+    check(f"rowln x splits{splits}", x_out, x_ref.float(), 2e-4, 2e-5)
+    check(f"rowln h splits{splits}", h_out, h_ref.float(), 2e-3, 2e-3)      # f16 output
+
+
 def test_profile_by_kernel_instantiation(eng):
     """sam2mi_profile_read_kernels: the per-instantiation accumulators (what bench.py's roofline object is built from) carry
     the rocprofv3 kernel names and add up to the family totals of sam2mi_profile_read."""
