@@ -182,22 +182,29 @@ __global__ void pool_tokens_kernel(const T* __restrict__ in, int ldin, T* __rest
 }
 
 // ------------------------------------------------------------------ token re-ordering between window sizes
-__global__ void permute_tokens_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C,
+// 4 channels per thread (C % 4 == 0); frame b of the output goes to dst.p[b] (the feature-cache slots of the frames are not
+// contiguous), or to out + b * H * W * C when dst.p[0] is null.
+__global__ void permute_tokens_kernel(const float* __restrict__ in, float* __restrict__ out, PermuteDst dst, int B, int H, int W, int C,
                                       int w_in, int w_out, const float* __restrict__ up, int w_up) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)B * H * W * C;
+  const int C4 = C >> 2;
+  const size_t total = (size_t)B * H * W * C4;
   if (i >= total) return;
-  const int c = (int)(i % C);
-  const size_t ot = i / C;
+  const int c = (int)(i % C4) * 4;
+  const size_t ot = i / C4;
   const int b = (int)(ot / ((size_t)H * W));
   const int t = (int)(ot % ((size_t)H * W));
   // destination token t (window size w_out) -> (y, x)
   const int ww = w_out * w_out, wpr = W / w_out;
   const int win = t / ww, in_w = t % ww;
   const int y = (win / wpr) * w_out + in_w / w_out, x = (win % wpr) * w_out + in_w % w_out;
-  float v = in[((size_t)b * H * W + tok_of_yx(y, x, W, w_in)) * C + c];
-  if (up) v += up[((size_t)b * (H / 2) * (W / 2) + tok_of_yx(y / 2, x / 2, W / 2, w_up)) * C + c];
-  out[i] = v;
+  f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)b * H * W + tok_of_yx(y, x, W, w_in)) * C + c);
+  if (up) {
+    const f32x4 u = *reinterpret_cast<const f32x4*>(up + ((size_t)b * (H / 2) * (W / 2) + tok_of_yx(y / 2, x / 2, W / 2, w_up)) * C + c);
+    v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+  }
+  float* ob = dst.p[0] ? dst.p[b] : out + (size_t)b * H * W * C;
+  *reinterpret_cast<f32x4*>(ob + (size_t)t * C + c) = v;
 }
 
 // ------------------------------------------------------------------ batched transpose through LDS
@@ -295,8 +302,11 @@ hipError_t pool_tokens_f16_launch(const half_t* in, int ldin, half_t* out, int l
   return hipGetLastError();
 }
 hipError_t permute_tokens_launch(const float* in, float* out, int B, int H, int W, int C, int w_in, int w_out,
-                                 const float* up, int w_up, hipStream_t s) {
-  permute_tokens_kernel<<<grid1d((size_t)B * H * W * C), dim3(256), 0, s>>>(in, out, B, H, W, C, w_in, w_out, up, w_up);
+                                 const float* up, int w_up, hipStream_t s, float* const* dst) {
+  if ((C & 3) || (dst && B > PermuteDst::MAX_B)) return hipErrorInvalidValue;
+  PermuteDst d;
+  for (int b = 0; b < PermuteDst::MAX_B; ++b) d.p[b] = (dst && b < B) ? dst[b] : nullptr;
+  permute_tokens_kernel<<<grid1d((size_t)B * H * W * (C / 4)), dim3(256), 0, s>>>(in, out, d, B, H, W, C, w_in, w_out, up, w_up);
   return hipGetLastError();
 }
 hipError_t transpose_f32_launch(const float* in, float* out, int batch, int R, int Cc, hipStream_t s) {

@@ -862,7 +862,7 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
     arena16.push_back({&(ptr), arena_elems});                                       \
     arena_elems += ((size_t)(count) + 127) / 128 * 128;                             \
   } while (0)
-  ALLOC(ctx->ws_x, float, T0 * E);
+  ALLOC(ctx->ws_x, float, T0 * 2 * E);               // same capacity as ws_x2: the two are swapped after a window re-ordering
   ALLOC(ctx->ws_x2, float, T0 * 2 * E);              // shortcut projection output (unpooled, 2C)
   ARENA16(ctx->ws_a16, T0 * 160);              // LN output (<= 144 ch) or im2col patches (160)
   ARENA16(ctx->ws_qk16, T0 * 4 * E);           // [M, 2*Cout], Cout up to 2E at stage-1 tokens (block 2)

@@ -253,7 +253,7 @@ static int trunk_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, const
       const int wn = ctx->blocks[i + 1].window;
       if (wn > 0 && wn != wcur) {
         CHK(permute_tokens_launch(ctx->ws_x, ctx->ws_x2, B, H, W, b.dim_out, wcur, wn, nullptr, 0, s));
-        CHK(hipMemcpyAsync(ctx->ws_x, ctx->ws_x2, (size_t)B * H * W * b.dim_out * sizeof(float), hipMemcpyDeviceToDevice, s));
+        std::swap(ctx->ws_x, ctx->ws_x2);                 // both buffers have the same capacity (engine_core.hip)
         wcur = wn;
       }
     }
@@ -281,25 +281,13 @@ int encoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, con
   int wlev[4];
   if (!img && !img_u8) return sam2mi_set_error(ctx, "encoder_forward", "no input frames");
   CHKI(trunk_forward(ctx, s, img, img_u8, B, wlev));
-  // level 2 (64x64): lateral + nearest-2x of level 3, to row-major tokens  (fpn_top_down_levels [2,3], scalp 1)
-  {
-    float* dst = ctx->ws_x;   // staging [B, 4096, 256]
-    CHK(permute_tokens_launch(ctx->ws_lat[2], dst, B, G / 4, G / 4, 256, wlev[2], G / 4, ctx->ws_lat[3], wlev[3], s));
-    for (int b = 0; b < B; ++b)
-      CHK(hipMemcpyAsync(outs[b].feat2, dst + (size_t)b * 4096 * 256, (size_t)4096 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  }
-  // level 1 (128x128, 64 channels) and level 0 (256x256, 32 channels): already conv_s1 / conv_s0 outputs, to row-major
-  {
-    float* dst = ctx->ws_x;
-    CHK(permute_tokens_launch(ctx->ws_lat[1], dst, B, G / 2, G / 2, 64, wlev[1], G / 2, nullptr, 0, s));
-    for (int b = 0; b < B; ++b)
-      CHK(hipMemcpyAsync(outs[b].fpn1, dst + (size_t)b * 16384 * 64, (size_t)16384 * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  }
-  {
-    float* dst = ctx->ws_x;
-    CHK(permute_tokens_launch(ctx->ws_lat[0], dst, B, G, G, 32, wlev[0], G, nullptr, 0, s));
-    for (int b = 0; b < B; ++b)
-      CHK(hipMemcpyAsync(outs[b].fpn0, dst + (size_t)b * 65536 * 32, (size_t)65536 * 32 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  }
+  // level 2 (64x64): lateral + nearest-2x of level 3, to row-major tokens  (fpn_top_down_levels [2,3], scalp 1); levels 1 (128x128,
+  // 64 channels) and 0 (256x256, 32 channels) are conv_s1 / conv_s0 outputs already.  Each frame goes straight to its own slot.
+  if (B > PermuteDst::MAX_B) return sam2mi_set_error(ctx, "encoder_forward", "batch exceeds the permute destination table");
+  float* d2[PermuteDst::MAX_B]; float* d1[PermuteDst::MAX_B]; float* d0[PermuteDst::MAX_B];
+  for (int b = 0; b < B; ++b) { d2[b] = outs[b].feat2; d1[b] = outs[b].fpn1; d0[b] = outs[b].fpn0; }
+  CHK(permute_tokens_launch(ctx->ws_lat[2], nullptr, B, G / 4, G / 4, 256, wlev[2], G / 4, ctx->ws_lat[3], wlev[3], s, d2));
+  CHK(permute_tokens_launch(ctx->ws_lat[1], nullptr, B, G / 2, G / 2, 64, wlev[1], G / 2, nullptr, 0, s, d1));
+  CHK(permute_tokens_launch(ctx->ws_lat[0], nullptr, B, G, G, 32, wlev[0], G, nullptr, 0, s, d0));
   return 0;
 }

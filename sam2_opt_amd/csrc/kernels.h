@@ -22,8 +22,9 @@ hipError_t pool_tokens_f32_launch(const float* in, int ldin, float* out, int ldo
 hipError_t pool_tokens_f16_launch(const half_t* in, int ldin, half_t* out, int ldout, int nwin, int w, int C, hipStream_t s);
 // reorder tokens of B grids (H x W) from window size w_in to window size w_out (w == W means row-major);
 // optional add of a nearest-2x-upsampled coarser grid `up` (H/2 x W/2, window size w_up).
+struct PermuteDst { static constexpr int MAX_B = 32; float* p[MAX_B]; };     // per-frame destinations of permute_tokens (p[0] null: contiguous `out`)
 hipError_t permute_tokens_launch(const float* in, float* out, int B, int H, int W, int C, int w_in, int w_out,
-                                 const float* up, int w_up, hipStream_t s);
+                                 const float* up, int w_up, hipStream_t s, float* const* dst = nullptr);
 // batched 2-D transpose f32: in [batch, R, Cc] -> out [batch, Cc, R]
 hipError_t transpose_f32_launch(const float* in, float* out, int batch, int R, int Cc, hipStream_t s);
 // out[m, c] += v[c] * (flag_ptr ? (1 - (flag[0] > 0)) : 1)

@@ -14,6 +14,25 @@ for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+if len(sys.argv) > 3 and sys.argv[3] == "enc":
+    # one image-encoder batch instead: from an im2col_patch launch to the next mem_assemble launch, consecutive equal launches folded
+    starts = [i for i, r in enumerate(rows) if "im2col_patch" in r[2]]
+    a = starts[-which]
+    b = next(i for i in range(a, len(rows)) if "mem_assemble_kernel" in rows[i][2])
+    seg, out, busy = rows[a:b], [], 0
+    for s, e, n in seg:
+        n = re.sub(r"\(anonymous namespace\)::", "", n)
+        n = re.sub(r"^void ", "", n)[:100]
+        busy += e - s
+        if out and out[-1][0] == n and abs(out[-1][1] / out[-1][2] - (e - s)) < 0.3 * (e - s):
+            out[-1][1] += e - s
+            out[-1][2] += 1
+        else:
+            out.append([n, e - s, 1])
+    for n, t, c in out:
+        print(f"{t / c / 1e3:8.1f} us x{c:3d}  {n}")
+    print(f"launches {len(seg)}  busy {busy / 1e3:.1f} us  wall {(seg[-1][1] - seg[0][0]) / 1e3:.1f} us")
+    sys.exit(0)
 starts = [i for i, r in enumerate(rows) if "mem_assemble_kernel" in r[2]]
 frames = []
 for a, b in zip(starts, starts[1:]):
