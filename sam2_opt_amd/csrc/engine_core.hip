@@ -84,13 +84,13 @@ static void prof_end_named(sam2mi_ctx* ctx, ProfAcc& a, const std::string& name,
 // X-stationary kernel for the encoder's short-K linears when the operands allow it
 bool xs_eligible(const sam2mi_ctx* ctx, const GemmParams& p) {
   static const int min_k = getenv("SAM2MI_XS_MINK") ? atoi(getenv("SAM2MI_XS_MINK")) : 0;      // A/B aid
-  return ctx->use_xs && p.K >= min_k && p.xs_pack && p.tile_hint == 0 && p.M >= 16384 && (p.ln_x32 ? p.ln_ld == p.K : p.lda == p.K) && gemm_xs_supported(p.N, p.K) &&
+  return ctx->use_xs && p.pool_w == 0 && p.K >= min_k && p.xs_pack && p.tile_hint == 0 && p.M >= 16384 && (p.ln_x32 ? p.ln_ld == p.K : p.lda == p.K) && gemm_xs_supported(p.N, p.K) &&
          (p.act == ACT_NONE || p.act == ACT_GELU) && p.rope_cols == 0 && p.res_mod == 0 && !p.outT32 && (p.n_split >= p.N || (p.n_split & 31) == 0) &&
          !(p.out32 && p.out16) && (p.out32 || p.out16) && (!p.res || p.out32) && p.bias &&
          (!p.col_scale || (p.xs_scale_cols > 0 && p.xs_scale_cols <= 576 && (p.xs_scale_cols + 31) / 32 * 32 <= p.n_split));
 }
 static bool ks_eligible(const sam2mi_ctx* ctx, const GemmParams& p) {
-  return ctx->use_ks && p.ks_pack && p.tile_hint == 0 && p.M >= 16384 && gemm_ks_supported(p.N, p.K) && p.act == ACT_NONE &&
+  return ctx->use_ks && p.pool_w == 0 && p.ks_pack && p.tile_hint == 0 && p.M >= 16384 && gemm_ks_supported(p.N, p.K) && p.act == ACT_NONE &&
          !p.col_scale && p.rope_cols == 0 && p.res_mod == 0 && p.out32 && !p.out16 && !p.outT16 && !p.outT32 && p.n_split >= p.N && p.bias;
 }
 // algorithmic HBM bytes of one linear: both operands read once (x2 planes in the split mode), every output written once, the
@@ -100,8 +100,9 @@ static double gemm_algo_bytes(const GemmParams& p) {
   const double planes = p.a_lo_off ? 2.0 : 1.0;
   double b = (p.ln_x32 ? 4.0 * mk : 2.0 * mk * planes) + 2.0 * nk * planes;
   const double row_cols = std::min(p.N, p.n_split), t_cols = p.N - row_cols;
-  if (p.out32) b += 4.0 * p.M * row_cols;
-  if (p.out16) b += 2.0 * p.M * row_cols * (p.out_lo_off ? 2.0 : 1.0);
+  const double out_rows = p.pool_w ? p.M / 4.0 : (double)p.M;       // fused 2x2 max-pool: a quarter of the rows is written
+  if (p.out32) b += 4.0 * out_rows * row_cols;
+  if (p.out16) b += 2.0 * out_rows * row_cols * (p.out_lo_off ? 2.0 : 1.0);
   if (p.outT16) b += 2.0 * p.M * t_cols * (p.out_lo_off ? 2.0 : 1.0);
   if (p.outT32) b += 4.0 * p.M * t_cols;
   if (p.res) b += 4.0 * mn;

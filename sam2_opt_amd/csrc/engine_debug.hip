@@ -51,7 +51,8 @@ extern "C" int sam2mi_debug_gemm(sam2mi_ctx* ctx, void* stream, const float* A, 
   GemmParams p = gemm_params_zero();
   p.a_lo_off = alo; p.w_lo_off = wlo;
   p.A = a16; p.lda = K; p.W = w16; p.ldw = K; p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act & 0xFF; p.n_split = N;
-  p.tile_hint = act >> 8;            // tests: force a tile / kernel variant
+  p.tile_hint = (act >> 8) & 0xFF;   // tests: force a tile / kernel variant
+  p.pool_w = act >> 16;              // fused 2x2 max-pool of the output rows (window side; out then has M / 4 rows)
   p.res = residual; p.ldres = N; p.out32 = out; p.ld32 = N;
   if (p.tile_hint == 31) {               // accumulator-stationary kernel (N = 576, K % 64 == 0)
     if (!gemm_ks_supported(N, K) || (act & 0xFF)) return sam2mi_set_error(ctx, __func__, "gemm_ks needs N == 576, K % 64 == 0, no activation");

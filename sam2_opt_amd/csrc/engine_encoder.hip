@@ -31,10 +31,15 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   if (b.q_pool) {
     // shortcut = maxpool2x2(proj(LN(x)))   (hieradet.py:139-140)
     GemmParams p = lin_params(ctx->ws_a16, C, M, b.sc);
-    p.out32 = ctx->ws_x2; p.ld32 = Co;
-    CHKI(run_gemm(ctx, s, p));
     Mq = M / 4;
-    CHK(pool_tokens_f32_launch(ctx->ws_x2, Co, x, Co, M / (wcur * wcur), wcur, Co, s));   // x is re-used: LN already consumed it
+    if (wcur <= 16 && (M & 31) == 0) {            // the pool runs in the GEMM epilogue: the unpooled [M, 2C] f32 tensor never exists
+      p.pool_w = wcur; p.out32 = x; p.ld32 = Co;            // x is re-used: LN already consumed it
+      CHKI(run_gemm(ctx, s, p));
+    } else {
+      p.out32 = ctx->ws_x2; p.ld32 = Co;
+      CHKI(run_gemm(ctx, s, p));
+      CHK(pool_tokens_f32_launch(ctx->ws_x2, Co, x, Co, M / (wcur * wcur), wcur, Co, s));
+    }
   }
   // 2. QKV projection: q|k row-major, v transposed (attention consumes V^T tiles)
   {

@@ -24,6 +24,10 @@ struct GemmParams {
   //   the pair (2p, 2p+1), p = (n % rope_dim) / 2, is rotated by the angle in table row m % rope_len
   const float* rope_cos; const float* rope_sin;  // [rope_len, rope_dim/2]
   int rope_len, rope_rows, rope_cols, rope_dim;
+  // 2x2 max-pool of the OUTPUT rows fused into the epilogue (gemm_v2 only; Hiera's shortcut  maxpool(proj(x)), hieradet.py:139-140):
+  // rows are tokens in window-major order with pool_w x pool_w windows (pool_w in {2,4,8,16}, 0: off); out32 / out16 then have
+  // M / 4 rows in window-major order with (pool_w/2)^2 windows.  Needs M % 32 == 0, N % 4 == 0, no residual / RoPE / transposed part.
+  int pool_w;
   int tile_hint;                 // 0 = automatic tile choice; 1..5 force a v2 tile (benchmarks)
   const half_t* xs_pack;         // W in the piece order of the X-stationary kernel (gemm_xs.hip), or null
   const half_t* ks_pack;         // W in the piece order of the accumulator-stationary kernel (gemm_ks.hip: N = 576), or null

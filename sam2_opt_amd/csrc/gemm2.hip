@@ -352,6 +352,25 @@ __global__ __launch_bounds__(WM * WN * 64, RS ? 4 : (WM * WN > 8 || SPLIT) ? 1 :
       for (int r = 0; r < 16; ++r) patch[acc_row(r, lane) * 32 + fr] = v[r];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const int c4 = (lane & 7) * 4;
+      if (p.pool_w) {                                               // 32 rows -> 8 pooled rows, one 16-B store per lane
+        const int w = p.pool_w, hw = w >> 1, pr = lane >> 3;
+        const int t = (pr / hw) * 2 * w + 2 * (pr % hw);            // top-left row of the quad inside the tile
+        const int m = mt0 + t, nn = nt0 + c4;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(patch + t * 32 + c4), b = *reinterpret_cast<const f32x4*>(patch + (t + 1) * 32 + c4);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(patch + (t + w) * 32 + c4), d = *reinterpret_cast<const f32x4*>(patch + (t + w + 1) * 32 + c4);
+        if (m < p.M && nn < p.N) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
+          const int ww = w * w, in_w = m % ww;
+          const size_t orow = (size_t)(m / ww) * (ww >> 2) + ((in_w / w) >> 1) * hw + ((in_w % w) >> 1);
+          if (p.out32) *reinterpret_cast<f32x4*>(p.out32 + orow * p.ld32 + nn) = o;
+          if (p.out16) store_h4(p.out16 + orow * p.ld16 + nn, p.out_lo_off, o);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int rr = (lane >> 3) + 8 * q;
@@ -451,6 +470,9 @@ static inline long tiles_of(const GemmParams& p, int bm, int bn) { return (long)
 // schedule, not more bytes per barrier).  The loop is bound by the per-CU L2->LDS rate (~25-29 B/clk) at these tiles.
 // The losing tiles are only compiled with -DSAM2MI_EXPERIMENTAL (tile_hint, tools/gemm_bench.py).
 hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
+  if (p.pool_w && ((p.pool_w != 2 && p.pool_w != 4 && p.pool_w != 8 && p.pool_w != 16) || (p.M & 31) || (p.N & 3) || (p.ld32 & 3) || (p.ld16 & 3) ||
+                   p.res || p.rope_cols > 0 || p.n_split < p.N || p.outT16 || p.outT32))
+    return hipErrorInvalidValue;                          // fused 2x2 max-pool: see gemm.h
   if (p.rope_cols > 0 && (p.rope_cols > p.n_split || (p.rope_cols & 3) || (p.rope_dim & 3) || (p.N & 3) || (p.ld32 & 3) || (p.ld16 & 3) ||
                           (p.ldres & 3) || p.rope_len <= 0))
     return hipErrorInvalidValue;                          // RoPE runs on the row-major 4-column phase of the epilogue

@@ -430,11 +430,11 @@ class Engine:
         return {f"{name}_ms": v[0].value, f"{name}_flops": v[1].value, f"{name}_launches": v[2].value}
 
     # ------------------------------------------------------------------ single-kernel debug entry points (tests)
-    def debug_gemm(self, A, W, bias=None, act=0, residual=None, tile_hint=0):
-        act = act | (tile_hint << 8)
+    def debug_gemm(self, A, W, bias=None, act=0, residual=None, tile_hint=0, pool_w=0):
+        act = act | (tile_hint << 8) | (pool_w << 16)
         M, K = A.shape
         N = W.shape[0]
-        out = self.new(M, N)
+        out = self.new(M // 4 if pool_w else M, N)
         self._check(self.lib.sam2mi_debug_gemm(self.h, self.stream, _ptr(A.contiguous()), _ptr(W.contiguous()), _ptr(bias), M, N, K,
                                                act, _ptr(residual), _ptr(out)), "sam2mi_debug_gemm")
         return out

@@ -154,6 +154,21 @@ def test_gemm_ks(eng, M, K, res):
     check(f"gemm_ks {M}x{N}x{K}", out, ref.float(), 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("w", [4, 8, 16])
+@pytest.mark.parametrize("M,N,K,hint", [(8192, 288, 144, 0), (4096, 576, 288, 13), (2048, 1152, 576, 5), (1024, 64, 64, 10)])
+def test_gemm_fused_maxpool(eng, M, N, K, hint, w):
+    """2x2 max-pool of window-major token rows inside the GEMM epilogue (the shortcut of a Hiera transition block,
+    hieradet.py:139-140: do_pool(self.proj(x), self.pool)) against torch: GEMM, then F.max_pool2d per window."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + w)
+    A = r16(torch.randn(M, K, generator=g)).cuda()
+    W = r16(torch.randn(N, K, generator=g) / math.sqrt(K)).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    out = eng.debug_gemm(A, W, b, 0, None, tile_hint=hint, pool_w=w)
+    full = (A.double() @ W.double().t() + b.double()).float()
+    ref = F.max_pool2d(full.view(M // (w * w), w, w, N).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).reshape(M // 4, N)
+    check(f"gemm+pool {M}x{N}x{K} w{w} hint{hint}", out, ref, 1e-4, 1e-5)
+
+
 @pytest.mark.parametrize("splits", [0, 1, 8])
 def test_rowln_fused_attention_tail(eng, splits):
     """gemm_rowln_kernel (combine of the flash partials + out-projection + residual + LayerNorm) against torch in f64."""
