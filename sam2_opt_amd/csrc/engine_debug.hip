@@ -215,6 +215,11 @@ extern "C" int sam2mi_debug_read(sam2mi_ctx* ctx, void* stream, const char* name
   else if (n == "d_big2") src = ctx->d_big2;
   else if (n == "t_pix") src = ctx->t_pix;
   else if (n == "m_out") src = ctx->m_out;
+  else if (n == "t_x") src = ctx->t_x;
+  else if (n == "t_kall16") src = reinterpret_cast<const float*>(ctx->t_kall16);       // f16 buffers: raw bits, count = halfs / 2
+  else if (n == "t_vTall16") src = reinterpret_cast<const float*>(ctx->t_vTall16);
+  else if (n == "t_kin16") src = reinterpret_cast<const float*>(ctx->t_kin16);
+  else if (n == "t_vin16") src = reinterpret_cast<const float*>(ctx->t_vin16);
   else return sam2mi_set_error(ctx, __func__, "unknown buffer");
   CHK(hipMemcpyAsync(out, src, (size_t)count * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   CHK(hipStreamSynchronize((hipStream_t)stream));

@@ -384,8 +384,12 @@ __global__ __launch_bounds__(WM * WN * 64, RS ? 4 : (WM * WN > 8 || SPLIT) ? 1 :
               const size_t ti = (size_t)tr * (p.rope_dim >> 1) + rope_pr[j];
               const float2 c = *reinterpret_cast<const float2*>(p.rope_cos + ti), sn = *reinterpret_cast<const float2*>(p.rope_sin + ti);
               const float a0 = o[0], a1 = o[1], a2 = o[2], a3 = o[3];
-              o[0] = a0 * c.x - a1 * sn.x; o[1] = a0 * sn.x + a1 * c.x;
-              o[2] = a2 * c.y - a3 * sn.y; o[3] = a2 * sn.y + a3 * c.y;
+              // scalar FMAs on purpose (the asm barriers keep the SLP vectoriser from forming v_pk_mul/fma_f32 with op_sel here)
+              float t0 = a1 * sn.x, t1 = a0 * sn.x, t2 = a3 * sn.y, t3 = a2 * sn.y;
+              asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+              o[0] = fmaf(a0, c.x, -t0); o[1] = fmaf(a1, c.x, t1);
+              o[2] = fmaf(a2, c.y, -t2); o[3] = fmaf(a3, c.y, t3);
+              asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
             }
             if (p.col_scale) {
 #pragma unroll

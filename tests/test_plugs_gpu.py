@@ -112,6 +112,17 @@ def test_memory_attention_full_bank(eng, sd_large, cfg_large):
     check("memattn_L7P64", got, ref, 5e-3, 2e-3)
 
 
+def test_memory_attention_is_deterministic(eng):
+    """The same call five times gives the same bits.  (Guards the RoPE epilogue of the K projection: a build whose compiler had
+    turned its rotation into packed-f32 ops lost one product on a few rows per call, differently every call - DESIGN.md 4.)"""
+    from sam2_opt_amd.synthetic import randn
+    inp = [t.cuda() for t in (randn(51, 4096, 1, 256), randn(52, 7, 4096, 1, 64), randn(53, 4096, 1, 256), randn(54, 7, 4096, 1, 64),
+                              randn(55, 64, 1, 64), randn(56, 64, 1, 64))]
+    outs = [eng.memory_attention(*inp).clone() for _ in range(5)]
+    for i, o in enumerate(outs[1:]):
+        assert torch.equal(o, outs[0]), f"call {i + 1} differs from call 0 on {(o != outs[0]).sum().item()} elements"
+
+
 @pytest.mark.parametrize("tag", ["maskdec_N1T8", "maskdec_N2T15"])
 def test_mask_decoder(eng, sd_large, cfg_large, tag):
     from oracle import sam2_ref as R
