@@ -18,6 +18,8 @@ Differences from the reference, all deliberate:
 """
 from __future__ import annotations
 
+import os
+
 import functools
 import threading
 from collections import OrderedDict
@@ -41,6 +43,9 @@ def _locked(fn):
             return fn(self, *a, **k)
     return wrapper
 
+
+# A/B switch (measurements only): queue the encoder prefetch BEFORE the tracking of the frame that triggers it (the round-1 order)
+_PREFETCH_EARLY = os.environ.get("SAM2MI_PREFETCH_EARLY") is not None
 
 class SAM2VideoPredictor:
     def __init__(self, model: str = "large", state_dict=None, ckpt_path: Optional[str] = None, device=None,
@@ -254,7 +259,13 @@ class SAM2VideoPredictor:
         slots = [self._free_feat_slots.pop() for _ in idxs]
 
         def run():
-            imgs = st["images"][idxs] if len(idxs) > 1 else st["images"][idxs[0]:idxs[0] + 1]
+            # consecutive frames (the usual case) are a view of the clip: no gather, and no host-blocking upload of an index tensor
+            # (which, queued behind the previous batch on the encoder stream, stalled the launching thread for a whole batch)
+            lo, hi = min(idxs), max(idxs)
+            if hi - lo + 1 == len(idxs):
+                imgs = st["images"][lo:hi + 1] if forward else st["images"][lo:hi + 1].flip(0)
+            else:
+                imgs = st["images"][idxs]
             if imgs.dtype == torch.uint8:                         # decoded HWC frames: normalised inside the engine
                 self.engine.video_encode_u8(imgs.to(self.device).contiguous(), slots)
             else:
@@ -278,7 +289,7 @@ class SAM2VideoPredictor:
             m[t] = sl
             self._feat_lru[(id(st), t)] = st
 
-    def _ensure_features(self, st, frame_idx: int, forward: bool = True) -> int:
+    def _ensure_features(self, st, frame_idx: int, forward: bool = True, prefetch: bool = True) -> int:
         """Feature-cache slot of `frame_idx`; on a miss encode a batch of frames starting there
         (cf. _get_image_feature :810-841, which caches exactly one frame).  With `overlap_encode` the batch AFTER the one
         in use is encoded ahead of time on the encoder stream."""
@@ -288,6 +299,15 @@ class SAM2VideoPredictor:
         ev = st["feat_events"].pop(frame_idx, None)
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
+        if prefetch:
+            self._prefetch_features(st, frame_idx, forward)
+        return m[frame_idx]
+
+    def _prefetch_features(self, st, frame_idx: int, forward: bool = True):
+        """With `overlap_encode`: queue the encoder pass of the batch after the one in use on the encoder stream.  propagate_in_video
+        calls this AFTER it has queued the tracking of `frame_idx`, so that the tracking stream is not left empty while the host
+        spends a millisecond enqueuing the ~350 launches of an encoder pass."""
+        m = st["feat_slot_of_frame"]
         if self.overlap_encode:
             step = 1 if forward else -1
             t = frame_idx + step
@@ -296,7 +316,6 @@ class SAM2VideoPredictor:
                 t += step
             if 0 <= t < st["num_frames"] and abs(t - frame_idx) <= ahead:
                 self._encode_batch(st, t, forward, side=True, keep=frame_idx)
-        return m[frame_idx]
 
     # ------------------------------------------------------------------ prompts
     @torch.inference_mode()
@@ -572,7 +591,7 @@ class SAM2VideoPredictor:
                     else:
                         todo.append(obj_idx)
                 if todo:
-                    feat = self._ensure_features(st, frame_idx, forward=not reverse)
+                    feat = self._ensure_features(st, frame_idx, forward=not reverse, prefetch=_PREFETCH_EARLY)
                 # the reference loops objects with B = 1 (:691-725); here up to 8 objects go through one batched pass
                 for c0 in range(0, len(todo), self.object_batch):
                     chunk = todo[c0:c0 + self.object_batch]
@@ -599,6 +618,8 @@ class SAM2VideoPredictor:
                                                                        object_score_logits=outs["object_score_logits"], has_mem=True, is_pts=False)
                         self._release_stale(st, obj_idx, od, frame_idx, reverse)
                         per_obj[obj_idx] = outs["low_res_masks"]
+                if todo and not _PREFETCH_EARLY:
+                    self._prefetch_features(st, frame_idx, forward=not reverse)      # after this frame's tracking has been queued
                 for obj_idx in range(len(st["obj_ids"])):
                     st["frames_tracked_per_obj"][obj_idx][frame_idx] = {"reverse": reverse}
                 low_all = torch.cat(per_obj, dim=0) if len(per_obj) > 1 else per_obj[0]
