@@ -531,18 +531,20 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
 // automatic tile: 3 = 128x192, 2 = 128x128, 1 = 128x64 (8 waves), 0 = 64x64 (4 waves), 4 = 64x64 with a 4-stage ring
 int gemm_v2_auto_tile(const GemmParams& p) {
   // long K, N a multiple of 192 (fc2 of stages 3-4: N = 576 / 1152): the 128x192 tile re-reads the A panel N/192 instead of
-  // N/64 times through the L2->LDS path that bounds this kernel (measured +14 % / +16 % on those two shapes)
-  if (p.N % 192 == 0 && p.K >= 2048 && p.M >= 4096) return 3;
+  // N/64 times through the L2->LDS path that bounds this kernel (measured +14 % / +16 % on those two shapes) - when it still fills
+  // the chip twice over (a batch-1 encoder call has 96 such tiles: 36.5 us vs 25.0 us on 64x64 tiles)
+  if (p.N % 192 == 0 && p.K >= 2048 && tiles_of(p, 128, 192) >= 512) return 3;
   const int n128 = ((p.N + 127) / 128) * 128;
   const long t128 = tiles_of(p, 128, 128);
   const bool fits128 = (n128 - p.N) * 100 <= 8 * p.N;              // N pads to 128 with at most 8 % waste
   if (fits128 && (t128 >= 1536 || (t128 >= 512 && p.K >= 2048))) return 2;
-  if (tiles_of(p, 128, 64) >= 1024) return 1;
-  // small grids (the M = 4096 GEMMs of the tracking path) run ~1 workgroup per CU with operands that the previous kernel has just
-  // written, i.e. served by the memory-side cache, not by the XCD's L2: with one K tile in flight the loop is latency-bound
-  // (ff2 of the memory attention, K = 2048: 26.6 us in the pipeline vs 13.9 us on L2-hot operands in tools/gemm_bench.py).  A
-  // 4-stage ring (3 tiles in flight) takes it to 16 us in the pipeline; no effect on L2-hot operands.
-  if (p.K >= 512) return 4;
+  if (tiles_of(p, 128, 64) >= 512) return 1;
+  // small grids (the M = 4096 GEMMs of the tracking path, stage 4 of a batch-1 encoder call) run ~1 workgroup per CU with operands
+  // that the previous kernel has just written, i.e. served by the memory-side cache, not by the XCD's L2: with one K tile in flight
+  // the loop is latency-bound (ff2 of the memory attention, K = 2048: 26.6 us in the pipeline vs 13.9 us on L2-hot operands in
+  // tools/gemm_bench.py).  A 4-stage ring (3 tiles in flight) takes it to 16 us in the pipeline.  Larger grids hide the latency with
+  // 3-4 workgroups of the 2-stage kernel per CU instead (stage-3 fc2 at batch 1, 576 tiles: 25.0 vs 33.1 us).
+  if (p.K >= 512 && tiles_of(p, 64, 64) <= 320) return 4;
   return 0;
 }
 

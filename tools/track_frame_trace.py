@@ -18,7 +18,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "enc":
     # one image-encoder batch instead: from an im2col_patch launch to the next mem_assemble launch, consecutive equal launches folded
     starts = [i for i, r in enumerate(rows) if "im2col_patch" in r[2]]
     a = starts[-which]
-    b = next(i for i in range(a, len(rows)) if "mem_assemble_kernel" in rows[i][2])
+    b = next((i for i in range(a + 1, len(rows)) if "mem_assemble_kernel" in rows[i][2] or "im2col_patch" in rows[i][2]), len(rows))
     seg, out, busy = rows[a:b], [], 0
     for s, e, n in seg:
         n = re.sub(r"\(anonymous namespace\)::", "", n)
