@@ -62,7 +62,9 @@ hipError_t flash256_init();   // dynamic-LDS attribute, once
 int flash256_pick_splits(int Nq, int Nk);   // KV splits that fill the chip once (<= 16: the size of the partial buffers)
 
 // ---- tiny fp32 attentions of the two-way mask decoder (attn_small.hip)
+// scratch (optional): partial results of the token -> image kernel that handles all T <= 8 queries of a prompt per workgroup
+// (batch * heads * Tk / 512 * Tq * 18 floats); without it the per-query kernel runs
 // q [Tq, ldq], k/v [Tk, ld], heads x hd, out [Tq, ldo]; all f32.  softmax(q k^T / sqrt(hd)) v
 hipError_t small_attn_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                              float* out, int ldo, int Tq, int Tk, int heads, int hd, int batch,
-                             size_t q_bstride, size_t kv_bstride, size_t o_bstride, hipStream_t stream);
+                             size_t q_bstride, size_t kv_bstride, size_t o_bstride, hipStream_t stream, float* scratch = nullptr, size_t scratch_floats = 0);

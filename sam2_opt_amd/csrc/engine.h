@@ -204,6 +204,7 @@ struct sam2mi_ctx {
   float* t_pix = nullptr;       // memory-conditioned features [4096, 256]
   // decoder
   float* d_keys = nullptr; half_t* d_keys16 = nullptr; half_t* d_kpe16 = nullptr;
+  float* d_t2i_part = nullptr; size_t d_t2i_part_floats = 0;      // split partials of the token -> image attention (attn_small.hip)
   float* d_tok = nullptr; float* d_tokpe = nullptr; float* d_t1 = nullptr; float* d_t2 = nullptr; float* d_t3 = nullptr;
   float* d_t4 = nullptr; float* d_big1 = nullptr; float* d_big2 = nullptr; float* d_big3 = nullptr; half_t* d_big16 = nullptr;
   float* d_tokens_in = nullptr; float* d_sparse = nullptr;

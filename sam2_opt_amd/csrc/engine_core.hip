@@ -909,6 +909,8 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ALLOC(ctx->d_tokpe, float, (size_t)DEC_MAX_N * 64 * 256);
   ALLOC(ctx->d_t1, float, (size_t)DEC_MAX_N * 64 * 2048);
   ALLOC(ctx->d_t2, float, (size_t)DEC_MAX_N * 64 * 2048);
+  ctx->d_t2i_part_floats = (size_t)DEC_MAX_N * 8 * 8 * 8 * 18;               // prompts x heads x 8 key splits x T <= 8 x (o[16], m, l)
+  ALLOC(ctx->d_t2i_part, float, ctx->d_t2i_part_floats);
   ALLOC(ctx->d_t3, float, (size_t)DEC_MAX_N * 64 * 2048);
   ALLOC(ctx->d_t4, float, (size_t)DEC_MAX_N * 64 * 2048);
   ALLOC(ctx->d_big1, float, (size_t)DEC_MAX_N * 4096 * 256);

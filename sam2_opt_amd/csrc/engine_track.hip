@@ -168,7 +168,7 @@ static int t2i_attention(sam2mi_ctx* ctx, hipStream_t s, const Lin32& Wq, const 
   pv.out32 = ctx->d_big2; pv.ld32 = 128;
   CHKI(run_gemm(ctx, s, pv));
   CHK(small_attn_launch(ctx->d_t1, 128, ctx->d_big1, 128, ctx->d_big2, 128, ctx->d_t2, 128, T, 4096, 8, 16, N, (size_t)T * 128,
-                        (size_t)4096 * 128, (size_t)T * 128, s));
+                        (size_t)4096 * 128, (size_t)T * 128, s, ctx->d_t2i_part, ctx->d_t2i_part_floats));
   // q = q + out_proj(att)
   CHKI(tok_linear(ctx, s, ctx->d_t2, 128, Wo, q, 256, R, 0, q, 256));
   return 0;
