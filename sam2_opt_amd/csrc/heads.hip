@@ -21,14 +21,31 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const SmallLinBatch B
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     if (vec) {
-      for (int k = lane * 4; k < D.K; k += 256) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
+      // 4 k-steps of 256 per trip, every load unconditional (rows past T re-read row T-1, k-steps past K read column 0 against a zero
+      // weight): with `if (t < T)` around each load the compiler kept one wait per token and k-step - 64 dependent round trips for
+      // K = 2048, the second linear of the token MLP: 23 us for 2 MB of weights
+      for (int k0 = lane * 4; k0 < D.K; k0 += 1024) {
+        f32x4 wv[4];
+        int ko[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = k0 + 256 * u < D.K;
+          ko[u] = ok ? k0 + 256 * u : 0;
+          wv[u] = *reinterpret_cast<const f32x4*>(wr + ko[u]);
+          if (!ok) wv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 xv[8][4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float* xr = D.x + (size_t)min(t0 + j, D.T - 1) * D.ldx;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xv[j][u] = *reinterpret_cast<const f32x4*>(xr + ko[u]);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          if (t0 + j < D.T) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(D.x + (size_t)(t0 + j) * D.ldx + k);
-            acc[j] += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
-          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            acc[j] += wv[u][0] * xv[j][u][0] + wv[u][1] * xv[j][u][1] + wv[u][2] * xv[j][u][2] + wv[u][3] * xv[j][u][3];
       }
     } else {
       for (int k = lane; k < D.K; k += 64) {
@@ -63,34 +80,29 @@ __global__ __launch_bounds__(1024) void mlp3_kernel(const Mlp3Batch B) {
   __shared__ __attribute__((aligned(16))) float buf[2][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // 16 waves
   if (tid < 256) buf[0][tid] = gx[tid];
-  __syncthreads();
 #pragma unroll 1
   for (int layer = 0; layer < 3; ++layer) {
     const float* W = G.W[layer];
     const float* b = G.b[layer];
     const int N = layer == 2 ? G.n_out : 256;
+    // each wave: outputs wave, wave+16, ...; ALL 16 rows of W of this wave are requested - unconditionally, rows past N re-read row
+    // N-1 - before the barrier that publishes the layer's input: one memory round trip per layer
+    f32x4 w[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) w[u] = *reinterpret_cast<const f32x4*>(W + (size_t)min(wave + 16 * u, N - 1) * 256 + lane * 4);
+    __syncthreads();
     const float* in = buf[layer & 1];
     const f32x4 xv = *reinterpret_cast<const f32x4*>(in + lane * 4);
-    // each wave: outputs wave, wave+16, ... ; 8 rows of W in flight per wave
-    for (int o0 = wave; o0 < N; o0 += 16 * 8) {
-      f32x4 w[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int o = o0 + 16 * u;
-        w[u] = (o < N) ? *reinterpret_cast<const f32x4*>(W + (size_t)o * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int o = o0 + 16 * u;
-        float v = wave_sum(w[u][0] * xv[0] + w[u][1] * xv[1] + w[u][2] * xv[2] + w[u][3] * xv[3]);
-        if (lane == 0 && o < N) {
-          v += b ? b[o] : 0.f;
-          if (layer < 2) buf[(layer + 1) & 1][o] = fmaxf(v, 0.f);
-          else gy[o] = G.sigmoid_out ? 1.f / (1.f + expf(-v)) : v;
-        }
+    for (int u = 0; u < 16; ++u) {
+      const int o = wave + 16 * u;
+      float v = wave_sum(w[u][0] * xv[0] + w[u][1] * xv[1] + w[u][2] * xv[2] + w[u][3] * xv[3]);
+      if (lane == 0 && o < N) {
+        v += b ? b[o] : 0.f;
+        if (layer < 2) buf[(layer + 1) & 1][o] = fmaxf(v, 0.f);
+        else gy[o] = G.sigmoid_out ? 1.f / (1.f + expf(-v)) : v;
       }
     }
-    __syncthreads();
   }
 }
 
