@@ -67,4 +67,5 @@ int flash256_pick_splits(int Nq, int Nk);   // KV splits that fill the chip once
 // q [Tq, ldq], k/v [Tk, ld], heads x hd, out [Tq, ldo]; all f32.  softmax(q k^T / sqrt(hd)) v
 hipError_t small_attn_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                              float* out, int ldo, int Tq, int Tk, int heads, int hd, int batch,
-                             size_t q_bstride, size_t kv_bstride, size_t o_bstride, hipStream_t stream, float* scratch = nullptr, size_t scratch_floats = 0);
+                             size_t q_bstride, size_t kv_bstride, size_t o_bstride, hipStream_t stream, float* scratch = nullptr, size_t scratch_floats = 0,
+                             half_t* out16 = nullptr, size_t out16_lo_off = 0);   // out16: image -> token case only, f16 output instead of `out`

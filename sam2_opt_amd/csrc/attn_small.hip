@@ -188,11 +188,12 @@ __global__ void t2i_merge_kernel(const float* __restrict__ part, float* __restri
 // keys/values of the head broadcast from LDS.
 __global__ __launch_bounds__(256) void i2t_attn_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                        const float* __restrict__ v, int ldv, float* __restrict__ out, int ldo,
-                                                       int Tq, int Tk, int heads, size_t q_bs, size_t kv_bs, size_t o_bs) {
+                                                       int Tq, int Tk, int heads, size_t q_bs, size_t kv_bs, size_t o_bs, half_t* out16, size_t lo_off) {
   constexpr int HD = 16;
   __shared__ float sk[64 * 128], sv[64 * 128];           // [Tk][heads*HD], heads*HD <= 128
   const int C = heads * HD;
-  q += blockIdx.y * q_bs; k += blockIdx.y * kv_bs; v += blockIdx.y * kv_bs; out += blockIdx.y * o_bs;     // batch
+  q += blockIdx.y * q_bs; k += blockIdx.y * kv_bs; v += blockIdx.y * kv_bs;     // batch
+  if (out16) out16 += blockIdx.y * o_bs; else out += blockIdx.y * o_bs;
   for (int i = threadIdx.x; i < Tk * C; i += 256) {
     sk[i] = k[(size_t)(i / C) * ldk + i % C];
     sv[i] = v[(size_t)(i / C) * ldv + i % C];
@@ -225,14 +226,17 @@ __global__ __launch_bounds__(256) void i2t_attn_kernel(const float* __restrict__
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     const f32x4 r = {o[4 * d] * inv, o[4 * d + 1] * inv, o[4 * d + 2] * inv, o[4 * d + 3] * inv};
-    *reinterpret_cast<f32x4*>(out + (size_t)qi * ldo + h * HD + 4 * d) = r;
+    if (out16) store_h4(out16 + (size_t)qi * ldo + h * HD + 4 * d, lo_off, r);         // the MFMA operand of the out-projection, directly
+    else *reinterpret_cast<f32x4*>(out + (size_t)qi * ldo + h * HD + 4 * d) = r;
   }
 }
 }  // namespace
 
 hipError_t small_attn_launch(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                              int Tq, int Tk, int heads, int hd, int batch, size_t q_bstride, size_t kv_bstride,
-                             size_t o_bstride, hipStream_t stream, float* scratch, size_t scratch_floats) {
+                             size_t o_bstride, hipStream_t stream, float* scratch, size_t scratch_floats, half_t* out16, size_t out16_lo_off) {
+  if (out16 && !(hd == 16 && batch <= 65535 && !(ldq & 3) && !(ldk & 3) && !(ldv & 3) && !(ldo & 3) && Tk <= 64 && heads * 16 <= 128 && Tq >= 1024))
+    return hipErrorInvalidValue;                          // f16 output: the image -> token kernel only
   const long tasks = (long)batch * heads * Tq;
   const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
   const bool al = !(ldq & 3) && !(ldk & 3) && !(ldv & 3) && !(ldo & 3);
@@ -253,7 +257,7 @@ hipError_t small_attn_launch(const float* q, int ldq, const float* k, int ldk, c
   }
   if (hd == 16 && batch <= 65535 && al && Tk <= 64 && heads * 16 <= 128 && Tq >= 1024) {
     i2t_attn_kernel<<<dim3((Tq * heads + 255) / 256, batch), dim3(256), 0, stream>>>(q, ldq, k, ldk, v, ldv, out, ldo, Tq, Tk, heads,
-                                                                                     q_bstride, kv_bstride, o_bstride);
+                                                                                     q_bstride, kv_bstride, o_bstride, out16, out16_lo_off);
     return hipGetLastError();
   }
   if (hd == 16)

@@ -109,6 +109,20 @@ __global__ void cast_add_vec_kernel(const float* __restrict__ a, int lda, const 
   if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)m * ldy32 + c) = v;
 }
 
+// y16 = f16(a), z16 = f16(a + b[m % bmod]) in one pass over a (the two image-side operands of the decoder's token <-> image attentions)
+__global__ void cast_pair_kernel(const float* __restrict__ a, const float* __restrict__ b, int bmod, int M, int C4, half_t* y16, half_t* z16,
+                                 size_t lo_off) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * C4) return;
+  const int m = (int)(i / C4), c = (int)(i % C4) * 4;
+  const size_t C = (size_t)C4 * 4;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(a + (size_t)m * C + c);
+  const f32x4 u = *reinterpret_cast<const f32x4*>(b + (size_t)(bmod ? m % bmod : m) * C + c);
+  store_h4(y16 + (size_t)m * C + c, lo_off, v);
+  const f32x4 w = {v[0] + u[0], v[1] + u[1], v[2] + u[2], v[3] + u[3]};
+  store_h4(z16 + (size_t)m * C + c, lo_off, w);
+}
+
 __global__ void cast_add_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int bmod,
                                 float sb, int M, int C, half_t* y16, int ldy16, float* y32, int ldy32, size_t lo_off) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,6 +295,11 @@ hipError_t cast_add_launch(const float* a, int lda, const float* b, int ldb, int
     cast_add_vec_kernel<<<grid1d((size_t)M * (C / 4)), dim3(256), 0, s>>>(a, lda, b, ldb, bmod, sb, M, C / 4, y16, ldy16, y32, ldy32, lo_off);
   else
     cast_add_kernel<<<grid1d((size_t)M * C), dim3(256), 0, s>>>(a, lda, b, ldb, bmod, sb, M, C, y16, ldy16, y32, ldy32, lo_off);
+  return hipGetLastError();
+}
+hipError_t cast_pair_launch(const float* a, const float* b, int bmod, int M, int C, half_t* y16, half_t* z16, hipStream_t s, size_t lo_off) {
+  if ((C & 3) || !a || !b || !y16 || !z16) return hipErrorInvalidValue;
+  cast_pair_kernel<<<grid1d((size_t)M * (C / 4)), dim3(256), 0, s>>>(a, b, bmod, M, C / 4, y16, z16, lo_off);
   return hipGetLastError();
 }
 hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStream_t s, size_t lo_off, int row_major) {

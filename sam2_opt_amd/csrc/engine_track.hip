@@ -139,8 +139,10 @@ static int tok_linear(sam2mi_ctx* ctx, hipStream_t s, const float* x, int ldx, c
   return 0;
 }
 static SmallLin mk_lin(const float* x, int ldx, const Lin32& L, float* y, int ldy, int T, int act, const float* res = nullptr,
-                       int ldres = 0) {
-  return SmallLin{x, L.w, L.b, y, res, ldx, ldy, ldres, T, L.N, L.K, act};
+                       int ldres = 0, const float* x2 = nullptr) {
+  SmallLin d{x, L.w, L.b, y, res, ldx, ldy, ldres, T, L.N, L.K, act};
+  d.x2 = x2;                                       // the linear runs on x + x2 (token + positional embedding, transformer.py:196,:204,:218)
+  return d;
 }
 static Mlp3Group mk_mlp3(const float* x, const Lin32* L, float* y, int sigmoid_out, long x_rep_stride = 0, long y_rep_stride = 0) {
   Mlp3Group g;
@@ -159,8 +161,12 @@ static int t2i_attention(sam2mi_ctx* ctx, hipStream_t s, const Lin32& Wq, const 
   float* q = ctx->d_tok;            // [N*T,256]
   const int R = N * T;
   // qq = q_proj(q + qpe)
-  CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, R, 256, nullptr, 0, ctx->d_tokpe, 256, s, ctx->lo16));
-  CHKI(tok_linear(ctx, s, ctx->d_tokpe, 256, Wq, ctx->d_t1, 128, R, 0));
+  {
+    SmallLinBatch B;
+    B.n = 1;
+    B.d[0] = mk_lin(q, 256, Wq, ctx->d_t1, 128, R, 0, nullptr, 0, ctx->d_tokens_in);
+    CHK(small_linear_batch_launch(B, s));
+  }
   GemmParams pk = lin_params(ctx->d_kpe16, 256, N * 4096, Wk);
   pk.out32 = ctx->d_big1; pk.ld32 = 128;
   CHKI(run_gemm(ctx, s, pk));
@@ -176,8 +182,7 @@ static int t2i_attention(sam2mi_ctx* ctx, hipStream_t s, const Lin32& Wq, const 
 
 // refresh the f16 image-side operands from ctx->d_keys [N*4096,256]: keys16 = f16(keys), kpe16 = f16(keys + pos)
 static int refresh_key_operands(sam2mi_ctx* ctx, hipStream_t s, const float* pos_tok, bool pos_shared, int N) {
-  CHK(cast_add_launch(ctx->d_keys, 256, nullptr, 0, 0, 0.f, N * 4096, 256, ctx->d_keys16, 256, nullptr, 0, s, ctx->lo16));
-  CHK(cast_add_launch(ctx->d_keys, 256, pos_tok, 256, pos_shared ? 4096 : 0, 1.f, N * 4096, 256, ctx->d_kpe16, 256, nullptr, 0, s, ctx->lo16));
+  CHK(cast_pair_launch(ctx->d_keys, pos_tok, pos_shared ? 4096 : 0, N * 4096, 256, ctx->d_keys16, ctx->d_kpe16, s, ctx->lo16));
   return 0;
 }
 
@@ -202,16 +207,12 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
   for (int l = 0; l < 2; ++l) {
     const DecLayerW& L = ctx->dec[l];
     // ---- token self attention (layer 0: no pe, output replaces the queries; transformer.py:186-193)
-    const float* qin = q;
-    if (l > 0) {
-      CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, R, 256, nullptr, 0, ctx->d_tokpe, 256, s, ctx->lo16));
-      qin = ctx->d_tokpe;
-    }
+    const float* qpe = l > 0 ? ctx->d_tokens_in : nullptr;          // q = k = queries + query_pe from the second layer on
     {
       SmallLinBatch B;
       B.n = 3;
-      B.d[0] = mk_lin(qin, 256, L.self_attn.q, ctx->d_t1, 256, R, 0);
-      B.d[1] = mk_lin(qin, 256, L.self_attn.k, ctx->d_t2, 256, R, 0);
+      B.d[0] = mk_lin(q, 256, L.self_attn.q, ctx->d_t1, 256, R, 0, nullptr, 0, qpe);
+      B.d[1] = mk_lin(q, 256, L.self_attn.k, ctx->d_t2, 256, R, 0, nullptr, 0, qpe);
       B.d[2] = mk_lin(q, 256, L.self_attn.v, ctx->d_t3, 256, R, 0);
       CHK(small_linear_batch_launch(B, s));
     }
@@ -232,17 +233,15 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
       GemmParams p = lin_params(ctx->d_kpe16, 256, M, L.i2t_q);
       p.out32 = ctx->d_big1; p.ld32 = 128;
       CHKI(run_gemm(ctx, s, p));
-      CHK(cast_add_launch(q, 256, ctx->d_tokens_in, 256, 0, 1.f, R, 256, nullptr, 0, ctx->d_tokpe, 256, s, ctx->lo16));
       {
         SmallLinBatch B;
         B.n = 2;
-        B.d[0] = mk_lin(ctx->d_tokpe, 256, L.i2t_k, ctx->d_t1, 128, R, 0);
+        B.d[0] = mk_lin(q, 256, L.i2t_k, ctx->d_t1, 128, R, 0, nullptr, 0, ctx->d_tokens_in);
         B.d[1] = mk_lin(q, 256, L.i2t_v, ctx->d_t2, 128, R, 0);
         CHK(small_linear_batch_launch(B, s));
       }
-      CHK(small_attn_launch(ctx->d_big1, 128, ctx->d_t1, 128, ctx->d_t2, 128, ctx->d_big2, 128, 4096, T, 8, 16, N, (size_t)4096 * 128,
-                            (size_t)T * 128, (size_t)4096 * 128, s));
-      CHK(cast_add_launch(ctx->d_big2, 128, nullptr, 0, 0, 0.f, M, 128, ctx->d_big16, 128, nullptr, 0, s, ctx->lo16));
+      CHK(small_attn_launch(ctx->d_big1, 128, ctx->d_t1, 128, ctx->d_t2, 128, nullptr, 128, 4096, T, 8, 16, N, (size_t)4096 * 128,
+                            (size_t)T * 128, (size_t)4096 * 128, s, nullptr, 0, ctx->d_big16, ctx->lo16));
       GemmParams o = lin_params(ctx->d_big16, 128, M, L.i2t_o);
       o.res = ctx->d_keys; o.ldres = 256; o.out32 = ctx->d_keys; o.ld32 = 256;
       CHKI(run_gemm(ctx, s, o));

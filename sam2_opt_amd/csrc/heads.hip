@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const SmallLinBatch B
   const int lane = threadIdx.x & 63;
   if (n >= D.N) return;
   const float* wr = D.W + (size_t)n * D.K;
-  const bool vec = ((D.K | D.ldx) & 3) == 0 && (((uintptr_t)D.x | (uintptr_t)D.W) & 15) == 0;
+  const bool vec = ((D.K | D.ldx) & 3) == 0 && (((uintptr_t)D.x | (uintptr_t)D.W | (uintptr_t)D.x2) & 15) == 0;
   for (int t0 = 0; t0 < D.T; t0 += 8) {
     float acc[8];
 #pragma unroll
@@ -37,9 +37,16 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const SmallLinBatch B
         f32x4 xv[8][4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float* xr = D.x + (size_t)min(t0 + j, D.T - 1) * D.ldx;
+          const size_t ro = (size_t)min(t0 + j, D.T - 1) * D.ldx;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) xv[j][u] = *reinterpret_cast<const f32x4*>(xr + ko[u]);
+          for (int u = 0; u < 4; ++u) xv[j][u] = *reinterpret_cast<const f32x4*>(D.x + ro + ko[u]);
+          if (D.x2) {                                               // wave-uniform
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const f32x4 e = *reinterpret_cast<const f32x4*>(D.x2 + ro + ko[u]);
+              xv[j][u][0] += e[0]; xv[j][u][1] += e[1]; xv[j][u][2] += e[2]; xv[j][u][3] += e[3];
+            }
+          }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const SmallLinBatch B
         const float wv = wr[k];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-          if (t0 + j < D.T) acc[j] += wv * D.x[(size_t)(t0 + j) * D.ldx + k];
+          if (t0 + j < D.T) acc[j] += wv * (D.x[(size_t)(t0 + j) * D.ldx + k] + (D.x2 ? D.x2[(size_t)(t0 + j) * D.ldx + k] : 0.f));
       }
     }
 #pragma unroll

@@ -10,6 +10,7 @@
 hipError_t layernorm_launch(const float* x, int ldx, const float* w, const float* b, float eps, int M, int C,
                             half_t* y16, int ldy16, float* y32, int ldy32, int act, hipStream_t s, size_t lo_off = 0);
 // y16[m, c] = f16(a[m, c] + sb * b[(m % bmod), c]);  b may be null; bmod == 0 -> m.  Optional y32 copy.
+hipError_t cast_pair_launch(const float* a, const float* b, int bmod, int M, int C, half_t* y16, half_t* z16, hipStream_t s, size_t lo_off = 0);   // y16 = f16(a), z16 = f16(a + b[m % bmod]); contiguous [M, C]
 hipError_t cast_add_launch(const float* a, int lda, const float* b, int ldb, int bmod, float sb, int M, int C,
                            half_t* y16, int ldy16, float* y32, int ldy32, hipStream_t s, size_t lo_off = 0);
 // patch-embed im2col: img [B,3,S,S] f32 -> A [B*(S/4)^2, 160] f16, rows in window-major (w=8) token order,
@@ -79,6 +80,7 @@ hipError_t small_linear_launch(const float* x, int ldx, const float* W, const fl
 struct SmallLin {
   const float* x; const float* W; const float* b; float* y; const float* res;
   int ldx, ldy, ldres, T, N, K, act;
+  const float* x2 = nullptr;     // optional second operand, same layout as x: the linear runs on x + x2 (token + positional embedding)
 };
 struct SmallLinBatch { SmallLin d[4]; int n; };
 hipError_t small_linear_batch_launch(const SmallLinBatch& B, hipStream_t s);
