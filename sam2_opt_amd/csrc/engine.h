@@ -208,6 +208,7 @@ struct sam2mi_ctx {
   float* d_tok = nullptr; float* d_tokpe = nullptr; float* d_t1 = nullptr; float* d_t2 = nullptr; float* d_t3 = nullptr;
   float* d_t4 = nullptr; float* d_big1 = nullptr; float* d_big2 = nullptr; float* d_big3 = nullptr; half_t* d_big16 = nullptr;
   float* d_tokens_in = nullptr; float* d_sparse = nullptr;
+  float* track_tokens = nullptr;   // [TRACK_MAX_N, 8, 256] constant decoder tokens of a prompt-free tracked frame (engine_core.hip)
   half_t* d_up1_16 = nullptr; half_t* d_up2_16 = nullptr; float* d_g = nullptr;
   float* d_hyper = nullptr; half_t* d_hyper16 = nullptr;
   float* d_fill_tmp = nullptr;     // [65536] hole-filling scratch

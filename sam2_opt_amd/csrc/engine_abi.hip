@@ -527,12 +527,12 @@ extern "C" int sam2mi_video_track(sam2mi_ctx* ctx, void* stream, int feat_slot, 
     // correction clicks on a tracked frame: memory-conditioned features + the user's points (+ previous mask logits)
     CHKI(build_tokens(ctx, s, prompt->coords, prompt->labels, 1, prompt->num_points, T));
   } else {
-    CHKI(build_tokens(ctx, s, nullptr, nullptr, 1, 0, T));      // no prompt: one padding point (label -1) + pad
-    // _forward_sam_heads pads with ONE (0,0)/-1 point and the prompt encoder appends another pad point (:395-401, prompt_encoder.py:133-137)
-    CHK(hipMemcpyAsync(ctx->d_sparse + (size_t)T * 256, ctx->d_sparse + (size_t)(T - 1) * 256, 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    T += 1;
+    // no prompt: _forward_sam_heads pads with ONE (0,0)/-1 point and the prompt encoder appends another pad point (:395-401,
+    // prompt_encoder.py:133-137) - both are the not_a_point embedding, so the 8 tokens are a constant built at weight-load time
+    T = 8;
   }
   DecoderIn in = one_image_in(ctx, f);
+  if (!has_pts) in.tokens = ctx->track_tokens;
   if (prompt && prompt->mask_logits) CHKI(one_image_in_mask(ctx, s, f, ctx->t_pix, prompt->mask_logits, in));
   CHKI(decoder_forward(ctx, s, in, 1, T));
   CHKI(sam_heads_finish(ctx, s, prompt ? prompt->multimask : 1, bank_slot, out, run_mem_encoder ? feat_slot : -1));
@@ -555,13 +555,8 @@ extern "C" int sam2mi_video_track_batch(sam2mi_ctx* ctx, void* stream, int feat_
   int Nk[TRACK_MAX_N], n_rope[TRACK_MAX_N];
   for (int n = 0; n < N; ++n) CHKI(assemble_object_memory(ctx, s, sels + n, n, Nk[n], n_rope[n]));
   CHKI(memattn_forward(ctx, s, f.feat2, ctx->sine_pe_tok64, N, Nk, n_rope, ctx->t_pix));
-  int T = 0;
-  CHKI(build_tokens(ctx, s, nullptr, nullptr, 1, 0, T));        // no prompt: one padding point + pad (as above), same for every object
-  CHK(hipMemcpyAsync(ctx->d_sparse + (size_t)T * 256, ctx->d_sparse + (size_t)(T - 1) * 256, 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  T += 1;
-  for (int n = 1; n < N; ++n)
-    CHK(hipMemcpyAsync(ctx->d_sparse + (size_t)n * T * 256, ctx->d_sparse, (size_t)T * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  DecoderIn in{ctx->t_pix, (size_t)4096 * 256, ctx->no_mask_embed, 1, 0, ctx->dense_pe, true, ctx->d_sparse, f.fpn0, 0, f.fpn1, 0};
+  const int T = 8;                                               // no prompt: the constant token set, the same for every object
+  DecoderIn in{ctx->t_pix, (size_t)4096 * 256, ctx->no_mask_embed, 1, 0, ctx->dense_pe, true, ctx->track_tokens, f.fpn0, 0, f.fpn1, 0};
   CHKI(decoder_forward(ctx, s, in, N, T));
   for (int n = 0; n < N; ++n) {
     const sam2mi_frame_out* out = outs ? outs + n : nullptr;

@@ -773,6 +773,25 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
       if (all) ctx->point_emb4 = dupload(ctx, t);
     }
     ctx->not_a_point = pk.f32(pe + "not_a_point_embed.weight");
+    {
+      // decoder tokens of a tracked frame without prompts, one copy per object of a batched pass: the six output tokens + two
+      // not-a-point rows (the (0,0)/-1 dummy point of _forward_sam_heads and the prompt encoder's padding point)
+      const HostW* a = pk.get(d + "obj_score_token.weight");
+      const HostW* b = pk.get(d + "iou_token.weight");
+      const HostW* m = pk.get(d + "mask_tokens.weight");
+      const HostW* nap = pk.get(pe + "not_a_point_embed.weight");
+      if (a && b && m && nap) {
+        std::vector<float> one;
+        one.insert(one.end(), a->data.begin(), a->data.end());
+        one.insert(one.end(), b->data.begin(), b->data.end());
+        one.insert(one.end(), m->data.begin(), m->data.end());
+        one.insert(one.end(), nap->data.begin(), nap->data.end());
+        one.insert(one.end(), nap->data.begin(), nap->data.end());
+        std::vector<float> t;
+        for (int n = 0; n < TRACK_MAX_N; ++n) t.insert(t.end(), one.begin(), one.end());
+        ctx->track_tokens = dupload(ctx, t);
+      }
+    }
     ctx->no_mask_embed = pk.f32(pe + "no_mask_embed.weight");
     ctx->mask_embed = MaskEmbedW{pk.f32(pe + "mask_downscaling.0.weight"), pk.f32(pe + "mask_downscaling.0.bias"),
                                  pk.f32(pe + "mask_downscaling.1.weight"), pk.f32(pe + "mask_downscaling.1.bias"),

@@ -157,14 +157,15 @@ static int tok_ln(sam2mi_ctx* ctx, hipStream_t s, float* x, const Norm& n, int T
 }
 
 // token -> image attention for N prompts: q tokens (+pe) against each prompt's image keys (f16 operands in d_kpe16 / d_keys16)
-static int t2i_attention(sam2mi_ctx* ctx, hipStream_t s, const Lin32& Wq, const Lin16& Wk, const Lin16& Wv, const Lin32& Wo, int N, int T) {
+static int t2i_attention(sam2mi_ctx* ctx, hipStream_t s, const Lin32& Wq, const Lin16& Wk, const Lin16& Wv, const Lin32& Wo, int N, int T,
+                         const float* query_pe) {
   float* q = ctx->d_tok;            // [N*T,256]
   const int R = N * T;
   // qq = q_proj(q + qpe)
   {
     SmallLinBatch B;
     B.n = 1;
-    B.d[0] = mk_lin(q, 256, Wq, ctx->d_t1, 128, R, 0, nullptr, 0, ctx->d_tokens_in);
+    B.d[0] = mk_lin(q, 256, Wq, ctx->d_t1, 128, R, 0, nullptr, 0, query_pe);
     CHK(small_linear_batch_launch(B, s));
   }
   GemmParams pk = lin_params(ctx->d_kpe16, 256, N * 4096, Wk);
@@ -201,13 +202,13 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
   for (int n = 0; n < N; ++n)
     CHK(cast_add_launch(in.keys_tok + (size_t)n * in.keys_stride, 256, in.dense_tok ? in.dense_tok + (size_t)n * in.dense_stride : nullptr, 256,
                         in.dense_rows >= 4096 ? 0 : 1, in.dense_tok ? 1.f : 0.f, 4096, 256, nullptr, 0, ctx->d_keys + (size_t)n * 4096 * 256, 256, s, ctx->lo16));
-  CHK(hipMemcpyAsync(ctx->d_tokens_in, in.tokens, (size_t)R * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));   // query_pe
+  const float* query_pe = in.tokens;             // the prompt tokens as they came in (transformer.py:128: query_pe = point_embedding), read-only
   CHK(hipMemcpyAsync(ctx->d_tok, in.tokens, (size_t)R * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
   float* q = ctx->d_tok;
   for (int l = 0; l < 2; ++l) {
     const DecLayerW& L = ctx->dec[l];
     // ---- token self attention (layer 0: no pe, output replaces the queries; transformer.py:186-193)
-    const float* qpe = l > 0 ? ctx->d_tokens_in : nullptr;          // q = k = queries + query_pe from the second layer on
+    const float* qpe = l > 0 ? query_pe : nullptr;          // q = k = queries + query_pe from the second layer on
     {
       SmallLinBatch B;
       B.n = 3;
@@ -222,7 +223,7 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
     CHKI(tok_ln(ctx, s, q, L.n1, R));
     // ---- tokens attend to the image
     CHKI(refresh_key_operands(ctx, s, in.pos_tok, in.pos_shared, N));
-    CHKI(t2i_attention(ctx, s, L.t2i_q, L.t2i_k, L.t2i_v, L.t2i_o, N, T));
+    CHKI(t2i_attention(ctx, s, L.t2i_q, L.t2i_k, L.t2i_v, L.t2i_o, N, T, query_pe));
     CHKI(tok_ln(ctx, s, q, L.n2, R));
     // ---- MLP on tokens
     CHKI(tok_linear(ctx, s, q, 256, L.mlp1, ctx->d_t1, 2048, R, 2));
@@ -236,7 +237,7 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
       {
         SmallLinBatch B;
         B.n = 2;
-        B.d[0] = mk_lin(q, 256, L.i2t_k, ctx->d_t1, 128, R, 0, nullptr, 0, ctx->d_tokens_in);
+        B.d[0] = mk_lin(q, 256, L.i2t_k, ctx->d_t1, 128, R, 0, nullptr, 0, query_pe);
         B.d[1] = mk_lin(q, 256, L.i2t_v, ctx->d_t2, 128, R, 0);
         CHK(small_linear_batch_launch(B, s));
       }
@@ -250,7 +251,7 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
   }
   // ---- final token -> image attention + LN (transformer.py:134-139)
   CHKI(refresh_key_operands(ctx, s, in.pos_tok, in.pos_shared, N));
-  CHKI(t2i_attention(ctx, s, ctx->fin_q, ctx->fin_k, ctx->fin_v, ctx->fin_o, N, T));
+  CHKI(t2i_attention(ctx, s, ctx->fin_q, ctx->fin_k, ctx->fin_v, ctx->fin_o, N, T, query_pe));
   CHKI(tok_ln(ctx, s, q, ctx->fin_norm, R));
   // hs = q: per prompt [0] obj score token, [1] iou token, [2..5] mask tokens
   CHK(hipMemcpy2DAsync(ctx->d_mtok, (size_t)4 * 256 * sizeof(float), q + 2 * 256, (size_t)T * 256 * sizeof(float), (size_t)4 * 256 * sizeof(float), N,
