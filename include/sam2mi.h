@@ -245,6 +245,8 @@ int sam2mi_debug_hiera_attention(sam2mi_ctx* ctx, void* stream, const float* q, 
                                  int heads, int GQ, int GK, int wq, int wk, float* out);
 int sam2mi_debug_rowln(sam2mi_ctx* ctx, void* stream, const float* a_or_parts, const float* ml, int splits, const float* W, const float* bias,
                        float* x, const float* ln_w, const float* ln_b, int M, float* h);
+int sam2mi_debug_projln(sam2mi_ctx* ctx, void* stream, const float* a, const float* W, const float* bias, float* x, const float* ln_w,
+                        const float* ln_b, int M, int C, float* h);
 int sam2mi_debug_flash256(sam2mi_ctx* ctx, void* stream, const float* q, const float* k, const float* v, int Nq, int Nk, float* out);
 int sam2mi_debug_hiera_block(sam2mi_ctx* ctx, void* stream, int block_idx, const float* x_nhwc, int B, float* out_nhwc);
 /* Hiera MLP x += fc2(GELU(fc1(xn))) on its own (f32 in, f16 MFMA operands): fused kernel (fused != 0) or the two-GEMM path;

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libsam2mi.so")
-SOURCES = ["gemm.hip", "gemm2.hip", "gemm_rowln.hip", "mlp_fused.hip", "gemm_xs.hip", "attn_hiera.hip", "attn_flash256.hip", "attn_precise.hip", "attn_small.hip",
+SOURCES = ["gemm.hip", "gemm2.hip", "gemm_rowln.hip", "gemm_projln.hip", "mlp_fused.hip", "gemm_xs.hip", "attn_hiera.hip", "attn_flash256.hip", "attn_precise.hip", "attn_small.hip",
            "elementwise.hip", "convs.hip", "heads.hip", "postproc.hip", "resize.hip", "hiera_generic.hip", "engine_core.hip", "engine_encoder.hip", "engine_track.hip",
            "engine_abi.hip", "engine_debug.hip"]
 # kernels that were measured and lost (DESIGN.md "GEMM tuning log"): only built with SAM2MI_EXPERIMENTAL=1 in the environment,

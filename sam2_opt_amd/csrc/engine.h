@@ -48,6 +48,7 @@ struct HieraBlockW {
   bool q_pool, stage_end;
   Norm n1, n2;
   Lin16 qkv, proj, fc1, fc2, sc;   // sc: dim-change shortcut projection (blocks 2, 8, 44)
+  half_t* proj_pack = nullptr;     // proj in the X-stationary piece order, for gemm_projln_kernel (proj + residual + norm2 in one launch)
   half_t* mlp_pack = nullptr;      // fc1 + fc2 in the fused MLP kernel's piece order (dim_out <= 288), mlp_fused_pack
   half_t* mlp_ln_pack = nullptr;   // the same with norm2 folded into fc1 (LN-fused operand load); fc1 bias = fc1.b_ln
   float* qscale = nullptr;         // [3*dim_out] column scale of the QKV GEMM: q columns *= 72^-0.5*log2(e), k/v columns 1
@@ -243,6 +244,7 @@ struct sam2mi_ctx {
   bool use_ks = false;             // accumulator-stationary GEMM for stage-3 fc2 (experimental, SAM2MI_KS=1; parity-tested, not faster end to end)
   bool use_xs = true;              // X-stationary GEMM for K <= 576 linears of the encoder (SAM2MI_NO_XS=1: tiled kernel)
   bool ln_fuse = false;            // LN1 / LN2 of Hiera blocks computed inside the consumer's operand load (opt-in: SAM2MI_LN_FUSE=1; no end-to-end gain)
+  bool use_projln = true;          // Hiera stages 1-3: out-projection + residual + norm2 in one kernel (SAM2MI_NO_PROJLN=1: GEMM + LayerNorm)
   bool use_rowln = true;           // memory attention: combine + out-projection + residual + next LayerNorm in one kernel (SAM2MI_NO_ROWLN=1: three kernels)
   bool use_fused_mlp = true;       // stages with C <= 288: one fused fc1-GELU-fc2 kernel (SAM2MI_NO_FUSED_MLP=1: two GEMMs, for A/B runs)
 };
@@ -263,6 +265,7 @@ int sam2mi_set_error(sam2mi_ctx* ctx, const char* what, const char* detail);
 void* dalloc(sam2mi_ctx* ctx, size_t bytes);
 int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p);                 // with profiling
 int run_rowln(sam2mi_ctx* ctx, hipStream_t s, const RowLnParams& p);               // gemm_rowln.hip, with profiling
+int run_projln(sam2mi_ctx* ctx, hipStream_t s, const ProjLnParams& p);             // gemm_projln.hip, with profiling
 bool xs_eligible(const sam2mi_ctx* ctx, const GemmParams& p);                      // will run_gemm take the X-stationary kernel?
 int run_hiera_attn(sam2mi_ctx* ctx, hipStream_t s, const HieraAttnParams& p);
 int run_mlp_fused(sam2mi_ctx* ctx, hipStream_t s, const MlpFusedParams& p, int C);     // with profiling

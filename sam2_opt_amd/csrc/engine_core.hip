@@ -180,6 +180,19 @@ int run_rowln(sam2mi_ctx* ctx, hipStream_t s, const RowLnParams& p) {
   return 0;
 }
 
+int run_projln(sam2mi_ctx* ctx, hipStream_t s, const ProjLnParams& p) {
+  hipEvent_t e0, e1;
+  if (ctx->prof_on) prof_begin(ctx, ctx->prof_gemm, s, e0, e1);
+  CHK(gemm_projln_launch(p, s));
+  if (ctx->prof_on) {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "gemm_projln_kernel<%d>", p.C);
+    // algorithmic bytes: f16 operand + weights + f32 residual in and out + f16 LayerNorm output
+    prof_end_named(ctx, ctx->prof_gemm, nm, s, e0, e1, 2.0 * p.M * (double)p.C * p.C, (double)p.M * p.C * (2 + 4 + 4 + 2) + 2.0 * p.C * p.C);
+  }
+  return 0;
+}
+
 int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p) {
   hipEvent_t e0, e1;
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_attn, s, e0, e1);
@@ -356,6 +369,7 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   ctx->use_fused_mlp = !ctx->precise && getenv("SAM2MI_NO_FUSED_MLP") == nullptr;
   ctx->use_xs = !ctx->precise && getenv("SAM2MI_NO_XS") == nullptr;
   ctx->use_rowln = !ctx->precise && getenv("SAM2MI_NO_ROWLN") == nullptr;
+  ctx->use_projln = !ctx->precise && getenv("SAM2MI_NO_PROJLN") == nullptr;
   // LayerNorm inside the operand load of the X-stationary / fused-MLP kernels: parity-tested, but measured EQUAL end to end
   // (205.6 vs 205.7 frames/s): the row is read twice as f32 by every column split, which costs what the separate LayerNorm
   // kernel cost (it runs at 5.5 TB/s) and moves more bytes past the L2.  Opt-in for A/B runs.
@@ -365,6 +379,7 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   if (e == hipSuccess) e = flash256_init();
   if (e == hipSuccess) e = mlp_fused_init();
   if (e == hipSuccess) e = gemm_xs_init();
+  if (e == hipSuccess) e = gemm_projln_init();
   if (e == hipSuccess) e = gemm_ks_init();
   if (e != hipSuccess) {
     sam2mi_set_error(nullptr, "gemm_init", hipGetErrorString(e));
@@ -518,6 +533,13 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
         if (!pk.ok || ctx->precise || !L->w || !gemm_xs_supported(L->N, L->K) || (L == &b.fc1 && mlp_fused_supported(b.dim_out))) continue;
         L->xs_pack = (half_t*)dalloc(ctx, gemm_xs_pack_bytes(L->N, L->K));
         if (!L->xs_pack || gemm_xs_pack(L->w, L->N, L->K, L->K, L->xs_pack, nullptr) != hipSuccess) pk.ok = false;
+      }
+      // stages 1-2 only by default: at C = 576 a 32-row workgroup streams the whole 663-KB weight from L2 with 9 KB per wave in flight
+      // and takes 89 us where GEMM + LayerNorm take 55 + 21 (C = 144: 184 vs 198 + 107 us, C = 288: 94 vs 106 + 41 us)
+      static const int projln_max_c = getenv("SAM2MI_PROJLN_MAXC") ? atoi(getenv("SAM2MI_PROJLN_MAXC")) : 288;
+      if (pk.ok && !ctx->precise && b.proj.w && b.proj.N == dim_out && b.proj.K == dim_out && gemm_projln_supported(dim_out) && dim_out <= projln_max_c) {
+        b.proj_pack = (half_t*)dalloc(ctx, gemm_xs_pack_bytes(dim_out, dim_out));      // out-projection + residual + norm2 in one kernel
+        if (!b.proj_pack || gemm_xs_pack(b.proj.w, dim_out, dim_out, dim_out, b.proj_pack, nullptr) != hipSuccess) pk.ok = false;
       }
       for (Lin16* L : {&b.fc2}) {       // stage 3 (N = 576, K = 2304): fc2 in the accumulator-stationary kernel's order (the projection, K = 576, is faster tiled)
         if (!pk.ok || ctx->precise || !L->w || !gemm_ks_supported(L->N, L->K)) continue;

@@ -177,6 +177,30 @@ extern "C" int sam2mi_debug_rowln(sam2mi_ctx* ctx, void* stream, const float* a_
   return 0;
 }
 
+// gemm_projln_kernel on its own: a [M, C] f32 (rounded to f16), W [C, C] f32 (rounded, packed), bias, residual x [M, C] (updated in place),
+// LayerNorm weights (eps 1e-6) -> h [M, C] f32 (from f16).  C in {144, 288, 576}, M % 32 == 0.
+extern "C" int sam2mi_debug_projln(sam2mi_ctx* ctx, void* stream, const float* a, const float* W, const float* bias, float* x, const float* ln_w,
+                                   const float* ln_b, int M, int C, float* h) {
+  if (!ctx) return 1;
+  if (!gemm_projln_supported(C)) return sam2mi_set_error(ctx, __func__, "C must be 144, 288 or 576");
+  hipStream_t s = (hipStream_t)stream;
+  Tmp t;
+  half_t* w16 = t.get<half_t>((size_t)C * C);
+  half_t* wpk = t.get<half_t>(gemm_xs_pack_bytes(C, C) / 2);
+  half_t* a16 = t.get<half_t>((size_t)M * C);
+  half_t* h16 = t.get<half_t>((size_t)M * C);
+  if (!w16 || !wpk || !a16 || !h16) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+  CHK(cast_add_launch(W, C, nullptr, 0, 0, 0.f, C, C, w16, C, nullptr, 0, s));
+  CHK(gemm_xs_pack(w16, C, C, C, wpk, s));
+  CHK(cast_add_launch(a, C, nullptr, 0, 0, 0.f, M, C, a16, C, nullptr, 0, s));
+  ProjLnParams q{a16, C, wpk, bias, x, x, ln_w, ln_b, 1e-6f, h16, C, M, C};
+  CHKI(run_projln(ctx, s, q));
+  f16_to_f32_kernel<<<dim3((unsigned)(((size_t)M * C + 255) / 256)), dim3(256), 0, s>>>(h16, h, (size_t)M * C);
+  CHK(hipGetLastError());
+  CHK(hipStreamSynchronize(s));
+  return 0;
+}
+
 // One Hiera block on x [B, H, W, C] (row-major NHWC, H = W = the grid of that block's stage) -> out NHWC
 extern "C" int sam2mi_debug_hiera_block(sam2mi_ctx* ctx, void* stream, int block_idx, const float* x_nhwc, int B, float* out_nhwc) {
   if (!ctx || !ctx->finalized) return sam2mi_set_error(ctx, __func__, "weights not finalized");

@@ -109,8 +109,12 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   }
   CHKI(run_hiera_attn(ctx, s, a));
   }
-  // 4. output projection + residual
-  {
+  // 4. output projection + residual (+ norm2 in the same kernel where a workgroup can own whole rows: stages 1-3, f16 mode)
+  const bool proj_ln = ctx->use_projln && !ctx->ln_fuse && b.proj_pack && (Mq & 31) == 0;
+  if (proj_ln) {
+    ProjLnParams q{ctx->ws_att16, Co, b.proj_pack, b.proj.b, xres, x, b.n2.w, b.n2.b, 1e-6f, ctx->ws_a16, Co, Mq, Co};
+    CHKI(run_projln(ctx, s, q));
+  } else {
     GemmParams p = lin_params(ctx->ws_att16, Co, Mq, b.proj);
     p.res = xres; p.ldres = Co; p.out32 = x; p.ld32 = Co;
     CHKI(run_gemm(ctx, s, p));
@@ -124,7 +128,7 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
       CHKI(run_mlp_fused(ctx, s, m, Co));
       return 0;
     }
-    CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s, ctx->lo16));
+    if (!proj_ln) CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s, ctx->lo16));
     MlpFusedParams m{ctx->ws_a16, Co, b.mlp_pack, b.fc1.b, b.fc2.b, x, Co, Mq};
     CHKI(run_mlp_fused(ctx, s, m, Co));
     return 0;
@@ -138,7 +142,7 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
       t.ln_x32 = x; t.ln_ld = Co; t.ln_eps = 1e-6f; t.xs_pack = b.fc1.xs_ln_pack; t.bias = b.fc1.b_ln;
       if ((fuse2 = xs_eligible(ctx, t))) p = t;
     }
-    if (!fuse2) CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s, ctx->lo16));
+    if (!fuse2 && !proj_ln) CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s, ctx->lo16));
     CHKI(run_gemm(ctx, s, p));
   }
   {

@@ -68,6 +68,20 @@ struct RowLnParams {
 };
 hipError_t gemm_rowln_launch(const RowLnParams& p, hipStream_t stream);
 
+// ---- Hiera out-projection + residual + norm2 in one kernel (gemm_projln.hip): N = K = C in {144, 288, 576}
+struct ProjLnParams {
+  const half_t* a16; int lda;        // attention output [M, C] f16
+  const half_t* wpack;               // proj weight [C, C] in the X-stationary piece order (gemm_xs_pack)
+  const float* bias;                 // [C]
+  const float* res; float* out32;    // out32 = res + a16 W^T + bias   [M, C] f32, contiguous rows (may alias)
+  const float* ln_w; const float* ln_b; float eps;
+  half_t* out16; int ld16;           // LayerNorm(out32) * ln_w + ln_b as f16
+  int M, C;                          // M % 32 == 0
+};
+bool gemm_projln_supported(int C);
+hipError_t gemm_projln_launch(const ProjLnParams& p, hipStream_t stream);
+hipError_t gemm_projln_init();       // dynamic-LDS attributes, once
+
 hipError_t gemm_v3_launch(const GemmParams& p, hipStream_t stream);
 hipError_t gemm_v3_init();
 // gemm4.hip: 256x256 staggered 4-phase kernel, one workgroup per CU (experimental; K % 64 == 0)

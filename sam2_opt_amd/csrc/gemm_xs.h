@@ -3,6 +3,10 @@
 #include <algorithm>
 #include "gemm.h"
 
+// packed weight image (gemm_xs_pack): 1-KiB pieces = MFMA fragment tiles of 32 rows x 16 k (unit l of a piece: row l / 2, k half
+// (l & 1) ^ ((row >> 3) & 1)); a stage = XS_STAGE_PIECES pieces (576 / K chunks of 32 columns x K / 16 k-steps) in XS_STAGE_SLOTS slots
+constexpr int XS_STAGE_PIECES = 36, XS_STAGE_SLOTS = 40;
+
 struct GemmXsParams {
   const half_t* x16; int ldx;      // [M, K] f16 activations (K-contiguous), ldx % 8 == 0
   const half_t* wpack;             // weight [N, K] in piece order (gemm_xs_pack)

@@ -32,9 +32,10 @@ static __device__ __forceinline__ const char* sgpr_ptr(const char* p) {
 }
 
 constexpr int NW = 8;                    // waves per workgroup = 8 token blocks of 32 (one workgroup per CU, two waves per SIMD)
-constexpr int STAGE_PIECES = 36;         // 1-KiB fragment pieces per ring stage ...
+constexpr int STAGE_PIECES = XS_STAGE_PIECES;     // 1-KiB fragment pieces per ring stage ...
 constexpr int PPW = (STAGE_PIECES + NW - 1) / NW;     // ... 5 per wave: the packed image pads every stage with 4 zero pieces
 constexpr int STAGE_SLOTS = PPW * NW;    // 40
+static_assert(STAGE_SLOTS == XS_STAGE_SLOTS, "packed image layout (gemm_xs.h)");
 constexpr int STAGE_B = STAGE_SLOTS * 1024;
 constexpr int NST = 3;                   // two stages in flight while one is consumed
 constexpr int MAX_COLS = 1152;           // output columns per workgroup (bias table in LDS)

@@ -20,7 +20,7 @@ EXPORTS = [
     "sam2mi_mask_decoder", "sam2mi_memory_encoder", "sam2mi_prompt_encoder", "sam2mi_prompt_encoder_ex", "sam2mi_dense_pe", "sam2mi_video_encode", "sam2mi_video_encode_u8", "sam2mi_fill_holes", "sam2mi_set_fill_hole_area",
     "sam2mi_video_click", "sam2mi_video_mask", "sam2mi_image_predict", "sam2mi_image_predict_ex", "sam2mi_video_encode_memory", "sam2mi_video_track", "sam2mi_video_track_batch", "sam2mi_resize_bilinear",
     "sam2mi_resize_u8_pil_bicubic", "sam2mi_resize_image_aa_bilinear", "sam2mi_stream_create_reserved", "sam2mi_stream_destroy", "sam2mi_profile_enable", "sam2mi_profile_read", "sam2mi_profile_read_mlp", "sam2mi_profile_read_xs", "sam2mi_profile_read_ks", "sam2mi_profile_read_kernels", "sam2mi_debug_gemm", "sam2mi_debug_hiera_attention",
-    "sam2mi_debug_flash256", "sam2mi_debug_rowln", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench", "sam2mi_debug_mlp",
+    "sam2mi_debug_flash256", "sam2mi_debug_rowln", "sam2mi_debug_projln", "sam2mi_debug_hiera_block", "sam2mi_debug_read", "sam2mi_debug_gemm_bench", "sam2mi_debug_flash_bench", "sam2mi_debug_mlp",
 ]
 
 
@@ -462,6 +462,15 @@ class Engine:
         self._check(self.lib.sam2mi_debug_rowln(self.h, self.stream, _ptr(a.contiguous()), _ptr(ml.contiguous()) if ml is not None else None, splits,
                                                 _ptr(W.contiguous()), _ptr(bias.contiguous()), _ptr(x), _ptr(ln_w.contiguous()), _ptr(ln_b.contiguous()),
                                                 M, _ptr(h)), "sam2mi_debug_rowln")
+        return x, h
+
+    def debug_projln(self, a, W, bias, x, ln_w, ln_b):
+        """gemm_projln_kernel: (x + a W^T + bias, LayerNorm of that (eps 1e-6) as the f16 values); a (M, C), W (C, C), C in {144, 288, 576}."""
+        M, Cc = a.shape
+        x = x.clone().contiguous()
+        h = self.new(M, Cc)
+        self._check(self.lib.sam2mi_debug_projln(self.h, self.stream, _ptr(a.contiguous()), _ptr(W.contiguous()), _ptr(bias.contiguous()), _ptr(x),
+                                                 _ptr(ln_w.contiguous()), _ptr(ln_b.contiguous()), M, Cc, _ptr(h)), "sam2mi_debug_projln")
         return x, h
 
     def debug_hiera_block(self, idx: int, x_nhwc: torch.Tensor, out_shape):

@@ -169,6 +169,21 @@ def test_gemm_fused_maxpool(eng, M, N, K, hint, w):
     check(f"gemm+pool {M}x{N}x{K} w{w} hint{hint}", out, ref, 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("M,C", [(4096, 144), (2048, 288), (1024, 576), (32, 576)])
+def test_projln_fused_projection_norm2(eng, M, C):
+    """gemm_projln_kernel (Hiera out-projection + residual + norm2, hieradet.py:161-165) against torch in f64 on f16-rounded operands."""
+    g = torch.Generator(device="cpu").manual_seed(M + C)
+    a = r16(torch.randn(M, C, generator=g)).cuda()
+    W = r16(torch.randn(C, C, generator=g) / math.sqrt(C)).cuda()
+    b, x = torch.randn(C, generator=g).cuda(), (3 * torch.randn(M, C, generator=g)).cuda()
+    lw, lb = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    x_ref = x.double() + a.double() @ W.double().t() + b.double()
+    h_ref = F.layer_norm(x_ref, (C,), lw.double(), lb.double(), 1e-6)
+    x_out, h_out = eng.debug_projln(a, W, b, x, lw, lb)
+    check(f"projln x {M}x{C}", x_out, x_ref.float(), 1e-4, 1e-5)
+    check(f"projln h {M}x{C}", h_out, h_ref.float(), 2e-3, 2e-3)      # f16 output
+
+
 @pytest.mark.parametrize("splits", [0, 1, 8])
 def test_rowln_fused_attention_tail(eng, splits):
     """gemm_rowln_kernel (combine of the flash partials + out-projection + residual + LayerNorm) against torch in f64."""
