@@ -146,6 +146,15 @@ def secondary_legs(args, pred, sd, cfg, frames, device):
             n = sum(1 for _ in trk.propagate())
             torch.cuda.synchronize()
         out["route_a_frames_per_s"] = round(n / (time.perf_counter() - t0), 2)
+        # BASELINE.json configs[1]: the image-encoder plug alone at batch 1 (what every frame of the drop-in route pays)
+        for _ in range(3):
+            trk.engine.image_encoder(fa[0:1].contiguous())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            trk.engine.image_encoder(fa[0:1].contiguous())
+        torch.cuda.synchronize()
+        out["config1_image_encoder_batch1_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
         out["route_a_note"] = (f"plug-level route (image encoder, memory attention, prompt encoder, mask decoder, memory encoder called one by one "
                                f"per frame with NCHW / sequence-first fp32 tensors, torch glue and memory bank): propagate loop over the first {nA} "
                                f"frames, precision={args.precision}; the headline `value` is the fused route (frame features and memory bank resident "
