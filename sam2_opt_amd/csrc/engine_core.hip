@@ -84,7 +84,7 @@ static void prof_end_named(sam2mi_ctx* ctx, ProfAcc& a, const std::string& name,
 // X-stationary kernel for the encoder's short-K linears when the operands allow it
 bool xs_eligible(const sam2mi_ctx* ctx, const GemmParams& p) {
   static const int min_k = getenv("SAM2MI_XS_MINK") ? atoi(getenv("SAM2MI_XS_MINK")) : 0;      // A/B aid
-  static const int min_m = getenv("SAM2MI_XS_MINM") ? atoi(getenv("SAM2MI_XS_MINM")) : 8192;       // batch-2 encoder calls: 9.27 vs 9.67 ms; batch 1 (M = 4096): slower (6.39 vs 6.24 ms)
+  static const int min_m = getenv("SAM2MI_XS_MINM") ? atoi(getenv("SAM2MI_XS_MINM")) : 16384;      // A/B aid: 8192 takes batch-2 encoder calls from 9.67 to 9.27 ms (batch 1, M = 4096: 6.24 -> 6.39), but then a 2-frame and a 1-frame pass of the same frame differ in the last bits
   return ctx->use_xs && p.pool_w == 0 && p.K >= min_k && p.xs_pack && p.tile_hint == 0 && p.M >= min_m && (p.ln_x32 ? p.ln_ld == p.K : p.lda == p.K) && gemm_xs_supported(p.N, p.K) &&
          (p.act == ACT_NONE || p.act == ACT_GELU) && p.rope_cols == 0 && p.res_mod == 0 && !p.outT32 && (p.n_split >= p.N || (p.n_split & 31) == 0) &&
          !(p.out32 && p.out16) && (p.out32 || p.out16) && (!p.res || p.out32) && p.bias &&
