@@ -244,6 +244,7 @@ struct sam2mi_ctx {
   bool use_ks = false;             // accumulator-stationary GEMM for stage-3 fc2 (experimental, SAM2MI_KS=1; parity-tested, not faster end to end)
   bool use_xs = true;              // X-stationary GEMM for K <= 576 linears of the encoder (SAM2MI_NO_XS=1: tiled kernel)
   bool ln_fuse = false;            // LN1 / LN2 of Hiera blocks computed inside the consumer's operand load (opt-in: SAM2MI_LN_FUSE=1; no end-to-end gain)
+  int ln1_fuse_maxc = 0;           // norm1 inside the operand load of the X-stationary QKV kernel for blocks with dim <= this (SAM2MI_LN1_FUSE_MAXC; 0: off)
   bool use_projln = true;          // Hiera stages 1-3: out-projection + residual + norm2 in one kernel (SAM2MI_NO_PROJLN=1: GEMM + LayerNorm)
   bool use_rowln = true;           // memory attention: combine + out-projection + residual + next LayerNorm in one kernel (SAM2MI_NO_ROWLN=1: three kernels)
   bool use_fused_mlp = true;       // stages with C <= 288: one fused fc1-GELU-fc2 kernel (SAM2MI_NO_FUSED_MLP=1: two GEMMs, for A/B runs)

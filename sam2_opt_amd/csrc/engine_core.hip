@@ -371,6 +371,9 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   ctx->use_xs = !ctx->precise && getenv("SAM2MI_NO_XS") == nullptr;
   ctx->use_rowln = !ctx->precise && getenv("SAM2MI_NO_ROWLN") == nullptr;
   ctx->use_projln = !ctx->precise && getenv("SAM2MI_NO_PROJLN") == nullptr;
+  // norm1 inside the operand load of the X-stationary QKV kernel: pays in stage 1 only (C = 144: the QKV launch goes 162 -> 200 us and the
+  // 107-us LayerNorm launch disappears; same box, 8-frame pass 28.14 -> 27.89 ms with 144, 27.98 with 288, worse with 576)
+  ctx->ln1_fuse_maxc = ctx->precise ? 0 : (getenv("SAM2MI_LN1_FUSE_MAXC") ? atoi(getenv("SAM2MI_LN1_FUSE_MAXC")) : 144);
   // LayerNorm inside the operand load of the X-stationary / fused-MLP kernels: parity-tested, but measured EQUAL end to end
   // (205.6 vs 205.7 frames/s): the row is read twice as f32 by every column split, which costs what the separate LayerNorm
   // kernel cost (it runs at 5.5 TB/s) and moves more bytes past the L2.  Opt-in for A/B runs.
@@ -566,7 +569,7 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
         folded = pk.lin16_raw(W, B, N, K);
       };
       Lin16 fc1_folded;
-      if (pk.ok && ctx->ln_fuse) {
+      if (pk.ok && (ctx->ln_fuse || dim <= ctx->ln1_fuse_maxc)) {
         if (b.qkv.xs_pack && dim == dim_out) {                 // not on dim-change blocks: their LN1 output also feeds the shortcut projection
           Lin16 f;
           fold_ln(p + "attn.qkv", p + "norm1", f);

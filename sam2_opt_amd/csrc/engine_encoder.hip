@@ -19,7 +19,7 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   // 1. LN1 - as a kernel of its own only when the QKV projection cannot normalise its operand rows itself
   GemmParams qkv_p = lin_params(ctx->ws_a16, C, M, b.qkv);
   bool fuse1 = false;
-  if (ctx->ln_fuse && b.qkv.xs_ln_pack) {
+  if ((ctx->ln_fuse || C <= ctx->ln1_fuse_maxc) && b.qkv.xs_ln_pack) {
     GemmParams t = qkv_p;                     // the launch below, with the LN-fused operand: does the X-stationary kernel take it?
     t.ln_x32 = x; t.ln_ld = C; t.ln_eps = 1e-6f; t.xs_pack = b.qkv.xs_ln_pack; t.bias = b.qkv.b_ln;
     t.n_split = 2 * Co; t.col_scale = b.qscale; t.xs_scale_cols = Co; t.out16 = ctx->ws_qk16; t.ld16 = 2 * Co; t.outT16 = ctx->ws_vT16; t.ldT16 = M;
