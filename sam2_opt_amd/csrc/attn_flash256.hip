@@ -418,6 +418,226 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
   }
 }
 
+#ifdef SAM2MI_EXPERIMENTAL
+// ---------------------------------------------------------------------------------------------------------------
+// v4: 64 queries per wave.  In v3 every wave reads the whole K and V^T tile from LDS (32 KB per tile and wave, 128 KB per CU)
+// for 32 MFMAs of 32 cycles: 1,024 cycles of LDS reads at the full 128 B/clk beside 1,024 cycles of MFMA - the two pipes are
+// balanced at their peaks, so neither gets there (measured 2,500 cycles per tile).  Here a wave owns TWO query tiles and every
+// K / V^T fragment it reads feeds two MFMAs: half the LDS bytes per FLOP.  Registers: Q 2 x 64, O 2 x 128 (accumulator
+// registers), scores 2 x 16, probabilities 2 x 8, fragments in batches of 8 - there is no room for the next tile's scores, so the
+// soft-max of a tile is not hidden behind the next tile's products as in v3; it is a tenth of the tile's MFMA time.
+// Same LDS image, ring and DMA schedule as v3; 256 queries per workgroup, so the split count doubles (16) to fill the chip.
+// MEASURED AND LOST (experimental build, SAM2MI_FLASH_V4=1; parity-green): 265-290 us against v3's 155 us on the cross-attention shape.
+// The 256 accumulation registers are all O, but the compiler gives every MFMA of a kernel that uses them an accumulation-register
+// destination - the two score tiles too - so each iteration parks O tiles in architectural registers and back (288 v_accvgpr_read +
+// 372 v_accvgpr_write per tile).  The structure needs hand-allocated registers (inline-asm MFMAs with their hazards managed by hand).
+template <bool MASK, int NST>
+__global__ __launch_bounds__(256, 1) void flash256_v4_kernel(const Flash256Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int qblocks = p.Nq >> 8;
+  const int pair = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = pair / qblocks;
+  const int q0 = (pair % qblocks) * 256 + wave * 64;
+  const int ntiles = (p.Nk + 31) / 32;
+  const int per = (ntiles + p.splits - 1) / p.splits;
+  const int t_lo = split * per, t_hi = min(ntiles, t_lo + per);
+  const int n = max(t_hi - t_lo, 0);
+
+  half8 qa[16], qb[16];
+  {
+    const half_t* qp = p.q + (size_t)(q0 + fr) * p.ldq + fh * 8;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      qa[s] = *reinterpret_cast<const half8*>(qp + s * 16);
+      qb[s] = *reinterpret_cast<const half8*>(qp + (size_t)32 * p.ldq + s * 16);
+    }
+  }
+  int k_src[4], v_src[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int kp = wave * 4 + j;
+    const int krow = kp * 2 + (lane >> 5), kpc = lane & 31;
+    k_src[j] = krow * p.ldk + ((kpc ^ (krow & 1)) << 3);
+    const int vp = wave * 4 + j;
+    const int vrow = vp * 16 + (lane >> 2), vpc = lane & 3;
+    v_src[j] = vrow * p.ldvT + ((vpc ^ ((vrow >> 2) & 3)) << 3);
+  }
+  auto issue = [&](int i) {
+    char* sb = smem + (i % NST) * STAGE3_B;
+    const int tile = t_lo + min(i, n - 1);
+    const half_t* kb = p.k + (size_t)tile * 32 * p.ldk;
+    const half_t* vb = p.vT + tile * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + k_src[j]), (lds_ptr_t)(sb + (wave * 4 + j) * K3_PIECE), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vb + v_src[j]), (lds_ptr_t)(sb + K3_TILE_B + (wave * 4 + j) * 1024), 16, 0, 0);
+    }
+  };
+  const int krow = pi23(fr);
+  const int krow_off = (krow >> 1) * K3_PIECE + (krow & 1) * 512 + ((fh ^ (krow & 1)) << 4);
+  // fragments in batches of 4 (16 registers), the next batch requested before the MFMAs of the current one: with Q (128) and the
+  // scores / probabilities (48) resident there is room for two batches, not for a whole tile as in v3
+  struct F2 { half8 f[2]; };
+  auto read_k2 = [&](int i, int b) {                     // k-steps 2 b, 2 b + 1
+    const char* sK = smem + (i % NST) * STAGE3_B + krow_off;
+    F2 k;
+    k.f[0] = *reinterpret_cast<const half8*>(sK + (2 * b) * 32);
+    k.f[1] = *reinterpret_cast<const half8*>(sK + (2 * b + 1) * 32);
+    return k;
+  };
+  const int vsw = (fr >> 2) & 3;
+  auto read_v2 = [&](int i, int t) {                     // d tile t: f[ks]
+    const char* sV = smem + (i % NST) * STAGE3_B + K3_TILE_B + fr * 64 + t * 2048;
+    F2 v;
+    v.f[0] = *reinterpret_cast<const half8*>(sV + (((0 + fh) ^ vsw) << 4));
+    v.f[1] = *reinterpret_cast<const half8*>(sV + (((2 + fh) ^ vsw) << 4));
+    return v;
+  };
+  auto rowmax = [&](const f32x16& s) {
+    float t = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) t = fmaxf(t, s[r]);
+    return fmaxf(t, __shfl_xor(t, 32, 64));
+  };
+
+  f32x16 oa[8], ob[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oa[t][r] = ob[t][r] = 0.f;
+  constexpr float RESCALE_THR = 8.f;
+  float ma = -1e30f, mb = -1e30f, la = 0.f, lb = 0.f;
+
+  // scores of ring tile i for both query tiles (after: tile i landed, every wave past tile i - 1); the DMA pieces of tile
+  // i + NST - 1 go out between the MFMAs
+  f32x16 sa, sb;
+  float ta = -1e30f, tb = -1e30f;
+  auto scores = [&](int i) {
+    wait_vm<8 * (NST - 2)>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sa[r] = sb[r] = 0.f;
+    // the scores live in ARCHITECTURAL registers: all 256 accumulation registers belong to O (left to itself the allocator puts the
+    // two score tiles there too and shuttles two O tiles through scratch every iteration, draining the DMA queue each time)
+    asm volatile("" : "+v"(sa), "+v"(sb));
+    F2 kc = read_k2(i, 0);
+    issue(i + NST - 1);
+#pragma unroll
+    for (int b2 = 0; b2 < 8; ++b2) {
+      F2 kn;
+      if (b2 < 7) kn = read_k2(i, b2 + 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        sa = mfma32(kc.f[j], qa[2 * b2 + j], sa);
+        sb = mfma32(kc.f[j], qb[2 * b2 + j], sb);
+      }
+      if (b2 < 7) kc = kn;
+      asm volatile("" : "+v"(sa), "+v"(sb));
+      __builtin_amdgcn_sched_barrier(0);                 // one batch ahead, no further: registers
+    }
+    if (MASK) {
+      const int nvalid = p.Nk - (t_lo + i) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (pi23(acc_row(r, lane)) >= nvalid) sa[r] = sb[r] = -1e30f;
+    }
+    ta = rowmax(sa);
+    tb = rowmax(sb);
+  };
+
+  if (n > 0) {
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) issue(t);
+    int i = 0;
+    scores(0);
+    for (;;) {
+      {                                                  // raise the reference maxima; the only place the VALU touches O (cf. v3)
+        const float na = fmaxf(ma, ta), nb = fmaxf(mb, tb);
+        const float aa = __builtin_amdgcn_exp2f(ma - na), ab = __builtin_amdgcn_exp2f(mb - nb);
+        la *= aa; lb *= ab;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { oa[t][r] *= aa; ob[t][r] *= ab; }
+        ma = na; mb = nb;
+      }
+      bool done = false;
+#pragma nounroll
+      for (;;) {
+        // here: sa / sb belong to tile i and stay within 2^8 of the reference maxima on every lane
+#pragma unroll
+        for (int t = 0; t < 8; ++t) asm volatile("" : "+a"(oa[t]), "+a"(ob[t]));       // O stays in the accumulation registers
+        half8 pa[2], pb[2];
+        {
+          float su = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float x = __builtin_amdgcn_exp2f(sa[r] - ma);
+            su += x;
+            pa[r >> 3][r & 7] = (half_t)x;
+          }
+          la += su + __shfl_xor(su, 32, 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          float su = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float x = __builtin_amdgcn_exp2f(sb[r] - mb);
+            su += x;
+            pb[r >> 3][r & 7] = (half_t)x;
+          }
+          lb += su + __shfl_xor(su, 32, 64);
+        }
+        // ---- O^T += V^T P^T for both query tiles
+        F2 vc = read_v2(i, 0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          F2 vn;
+          if (t < 7) vn = read_v2(i, t + 1);
+          oa[t] = mfma32(vc.f[0], pa[0], oa[t]);
+          ob[t] = mfma32(vc.f[0], pb[0], ob[t]);
+          oa[t] = mfma32(vc.f[1], pa[1], oa[t]);
+          ob[t] = mfma32(vc.f[1], pb[1], ob[t]);
+          if (t < 7) vc = vn;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        ++i;
+        if (i >= n) { done = true; break; }
+        scores(i);
+        if (__any(ta > ma + RESCALE_THR || tb > mb + RESCALE_THR)) break;
+      }
+      if (done) break;
+    }
+  }
+  wait_vm<0>();                                          // the trailing (duplicate) DMA pieces must land before the LDS is released
+
+  // ---- partial results of the two query tiles
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int q = q0 + 32 * h + fr;
+    float* op = p.o_part + ((size_t)split * p.Nq + q) * D;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x16& o = h ? ob[t] : oa[t];
+        const f32x4 v = {o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+        *reinterpret_cast<f32x4*>(op + t * 32 + 8 * g + 4 * fh) = v;
+      }
+    if (fh == 0) {
+      float* ml = p.ml_part + ((size_t)split * p.Nq + q) * 2;
+      ml[0] = h ? mb : ma;
+      ml[1] = h ? lb : la;
+    }
+  }
+}
+
+#endif  // SAM2MI_EXPERIMENTAL (v4)
+
 // 64 threads per query (4 channels each), 4 queries per workgroup
 __global__ __launch_bounds__(256) void flash256_combine_kernel(const Flash256Params p) {
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6), d = (threadIdx.x & 63) * 4;
@@ -449,6 +669,10 @@ hipError_t flash256_init() {
     hipError_t e = hipFuncSetAttribute(v3[i], hipFuncAttributeMaxDynamicSharedMemorySize, NST_MAX * STAGE3_B);
     if (e != hipSuccess) return e;
   }
+  for (const void* f : {reinterpret_cast<const void*>(&flash256_v4_kernel<false, 4>), reinterpret_cast<const void*>(&flash256_v4_kernel<true, 4>)}) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, NST_MAX * STAGE3_B);
+    if (e != hipSuccess) return e;
+  }
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&flash256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B);
 #else
   const void* v3[2] = {reinterpret_cast<const void*>(&flash256_v3_kernel<0, false, 4>), reinterpret_cast<const void*>(&flash256_v3_kernel<0, true, 4>)};
@@ -461,8 +685,21 @@ hipError_t flash256_init() {
 }
 
 // v3 runs one 128-query workgroup per CU: pick the KV split count that makes the grid one full wave of 256 workgroups
+// long key sequences with Nq a multiple of 256 take the 64-queries-per-wave kernel (256 queries per workgroup)
+bool flash256_use_v4(int Nq, int Nk) {
+#ifdef SAM2MI_EXPERIMENTAL
+  static const bool on = getenv("SAM2MI_FLASH_V4") != nullptr;          // measured slower (see flash256_v4_kernel): opt-in, experimental build
+  return on && Nq % 256 == 0 && Nk >= 8192;
+#else
+  (void)Nq; (void)Nk;
+  return false;
+#endif
+}
+
+// one workgroup per CU: pick the KV split count that makes the grid one full wave of 256 workgroups
 int flash256_pick_splits(int Nq, int Nk) {
-  const int tiles = (Nk + 31) / 32, qblocks = Nq / 128 > 0 ? Nq / 128 : 1;
+  const int qb = flash256_use_v4(Nq, Nk) ? 256 : 128;
+  const int tiles = (Nk + 31) / 32, qblocks = Nq / qb > 0 ? Nq / qb : 1;
 #ifdef SAM2MI_EXPERIMENTAL
   static const int target_wgs = getenv("SAM2MI_FLASH_WGS") ? atoi(getenv("SAM2MI_FLASH_WGS")) : 256;     // tuning
 #else
@@ -495,6 +732,13 @@ hipError_t flash256_launch(const Flash256Params& p, hipStream_t stream) {
 #endif
   {
     const size_t lds = (size_t)4 * STAGE3_B;
+#ifdef SAM2MI_EXPERIMENTAL
+    if (flash256_use_v4(p.Nq, p.Nk)) {
+      const dim3 grid4((p.Nq / 256) * p.splits);
+      if (p.Nk % 32) flash256_v4_kernel<true, 4><<<grid4, block, lds, stream>>>(p);
+      else flash256_v4_kernel<false, 4><<<grid4, block, lds, stream>>>(p);
+    } else
+#endif
     if (p.Nk % 32) flash256_v3_kernel<0, true, 4><<<grid, block, lds, stream>>>(p);
     else flash256_v3_kernel<0, false, 4><<<grid, block, lds, stream>>>(p);
   }
