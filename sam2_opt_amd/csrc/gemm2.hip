@@ -530,10 +530,11 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
 
 // automatic tile: 3 = 128x192, 2 = 128x128, 1 = 128x64 (8 waves), 0 = 64x64 (4 waves), 4 = 64x64 with a 4-stage ring
 int gemm_v2_auto_tile(const GemmParams& p) {
-  // long K, N a multiple of 192 (fc2 of stages 3-4: N = 576 / 1152): the 128x192 tile re-reads the A panel N/192 instead of
+  // long K, N a multiple of 192: fc2 of stages 3-4 (K >= 2048), QKV and fc1 of stage 4 (K = 1152, N = 3456 / 4608: 91 vs 96, 119 vs 132 us;
+  // the stage-4 projection, N = K = 1152, stays on 128x64: 43 vs 50 us): the 128x192 tile re-reads the A panel N/192 instead of
   // N/64 times through the L2->LDS path that bounds this kernel (measured +14 % / +16 % on those two shapes) - when it still fills
   // the chip (a batch-1 encoder call has 96 such tiles: 36.5 us vs 25.0 us on 64x64 tiles)
-  if (p.N % 192 == 0 && p.K >= 2048 && tiles_of(p, 128, 192) >= 320) return 3;      // stage-4 fc2 at batch 8: 384 tiles, 121 vs 138 us on 128x128
+  if (p.N % 192 == 0 && (p.K >= 2048 || (p.K >= 1024 && p.N >= 2304)) && tiles_of(p, 128, 192) >= 320) return 3;      // stage-4 fc2 at batch 8: 384 tiles, 121 vs 138 us on 128x128
   const int n128 = ((p.N + 127) / 128) * 128;
   const long t128 = tiles_of(p, 128, 128);
   const bool fits128 = (n128 - p.N) * 100 <= 8 * p.N;              // N pads to 128 with at most 8 % waste
