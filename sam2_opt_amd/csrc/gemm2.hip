@@ -538,7 +538,7 @@ int gemm_v2_auto_tile(const GemmParams& p) {
   const int n128 = ((p.N + 127) / 128) * 128;
   const long t128 = tiles_of(p, 128, 128);
   const bool fits128 = (n128 - p.N) * 100 <= 8 * p.N;              // N pads to 128 with at most 8 % waste
-  if (fits128 && (t128 >= 1536 || (t128 >= 512 && p.K >= 2048))) return 2;
+  if (fits128 && p.K > 64 && (t128 >= 1536 || (t128 >= 512 && p.K >= 2048))) return 2;      // K = 64 (one K tile: all prologue and epilogue): 128x64, more workgroups in flight
   if (tiles_of(p, 128, 64) >= 512) return 1;
   // small grids (the M = 4096 GEMMs of the tracking path, stage 4 of a batch-1 encoder call) run ~1 workgroup per CU with operands
   // that the previous kernel has just written, i.e. served by the memory-side cache, not by the XCD's L2: with one K tile in flight
