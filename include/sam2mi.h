@@ -44,15 +44,22 @@ typedef struct sam2mi_config {
   int precision;             /* SAM2MI_PRECISION_F16 (0, default): f16 MFMA operands, f32 accumulate - masks within ~2e-3 of the
                               * reference's fp32 torch path; SAM2MI_PRECISION_F16X3 (1): every MFMA operand is carried as a
                               * 2-term f16 split (hi + lo) and every product costs three MFMAs - the north-star "within 1e-3"
-                              * class (measured <= 1e-4 per plug), about 2-3x the MFMA work */
+                              * class (measured <= 1e-4 per plug), about 2-3x the MFMA work;
+                              * SAM2MI_PRECISION_F16S (2): SELECTIVE split - the same "within 1e-3" class at a fraction of the
+                              * cost: only the operands whose rounding carries the error are split (weights of the encoder's
+                              * attention linears and of stages 1-2, the attention output and q / k; every linear of the
+                              * tracking path), the rest runs as in the f16 mode (tools/precision_shares.py) */
 } sam2mi_config;
 #define SAM2MI_PRECISION_F16 0
 #define SAM2MI_PRECISION_F16X3 1
+#define SAM2MI_PRECISION_F16S 2
 
 int sam2mi_abi_version(void);
 int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out);
 void sam2mi_destroy(sam2mi_ctx* ctx);
-const char* sam2mi_last_error(sam2mi_ctx* ctx);   /* ctx may be NULL: last creation error */
+/* Message of the last failed call OF THE CALLING THREAD (errno-style, thread-local: a context may be driven from several host
+ * threads at once); ctx may be NULL (creation errors).  Valid until the thread's next failing call. */
+const char* sam2mi_last_error(sam2mi_ctx* ctx);
 
 /* Weight loading - replaces build_sam._load_checkpoint (build_sam.py:164-174): call once per
  * state_dict entry with a HOST pointer to fp32 data, then sam2mi_finalize_weights (packs f16 MFMA
@@ -109,7 +116,10 @@ int sam2mi_dense_pe(sam2mi_ctx* ctx, void* stream, float* out);
  *   Image.resize((S,S)) = separable bicubic (a = -0.5, support stretched when shrinking), 22-bit fixed-point coefficients, a uint8
  *   rounding after each pass; out [S,S,3] uint8, bit-exact against Pillow.  Feed it to sam2mi_video_encode_u8.
  * sam2mi_resize_image_aa_bilinear - SAM2Transforms (utils/transforms.py:27-41): ToTensor (/255) + torchvision Resize on a float
- *   tensor = antialiased bilinear (aten _upsample_bilinear2d_aa); out [3,S,S] f32 in [0,1] (what set_image_e2e takes). */
+ *   tensor = antialiased bilinear (aten _upsample_bilinear2d_aa); out [3,S,S] f32 in [0,1] (what set_image_e2e takes).
+ * The FIRST call with a new (in, out) size pair allocates its coefficient tables (hipMalloc: may synchronise the device once) and
+ * uploads them asynchronously on `stream`; a frame larger than any before re-allocates the scratch buffer (hipFree: waits for
+ * the device).  Every other call only launches two kernels on `stream`. */
 int sam2mi_resize_u8_pil_bicubic(sam2mi_ctx* ctx, void* stream, const uint8_t* in, int H, int W, uint8_t* out, int S);
 int sam2mi_resize_image_aa_bilinear(sam2mi_ctx* ctx, void* stream, const uint8_t* in, int H, int W, float* out, int S);
 

@@ -108,7 +108,10 @@ struct DomainGuard {
   }
 };
 
-struct ResizeTable { int* bounds = nullptr; void* coef = nullptr; int ksize = 0; };     // resize.hip: per (kind, in, out) size triple
+struct ResizeTable {                 // resize.hip: per (kind, in, out) size triple; the host copies back the asynchronous upload
+  int* bounds = nullptr; void* coef = nullptr; int ksize = 0;
+  std::vector<int> h_bounds; std::vector<char> h_coef;
+};
 
 struct sam2mi_ctx {
   sam2mi_config cfg;
@@ -116,7 +119,8 @@ struct sam2mi_ctx {
   std::unordered_map<uint64_t, ResizeTable> resize_tables;
   void* resize_tmp = nullptr;
   size_t resize_tmp_bytes = 0;
-  std::string err;
+  std::mutex misc_mu;               // ctx->allocs (run-time allocations may come from both domains)
+  std::mutex prof_mu;               // the profiling accumulators below
   bool finalized = false;
   std::unordered_map<std::string, HostW> hw;     // host copies until finalize
   std::vector<void*> allocs;
@@ -170,7 +174,8 @@ struct sam2mi_ctx {
 
   // ---- precision mode (sam2mi_config.precision).  f16x3: every f16 activation buffer below lives in ONE arena whose second
   // half holds the lo planes, so `lo16` (elements) is the hi -> lo distance of all of them; 0 in the default f16 mode.
-  bool precise = false;
+  bool precise = false;        // f16x3 or f16s: lo planes exist (arena, packed weights)
+  bool selective = false;      // f16s: per-linear plan (GemmParams.prec); everything not planned runs as in f16x3
   size_t lo16 = 0;
   float* ws_qk32 = nullptr;    // f16x3 mode: q|k and V^T of the Hiera blocks in f32 (operands of attn_precise.hip)
   float* ws_vT32 = nullptr;
@@ -264,6 +269,8 @@ int sam2mi_set_error(sam2mi_ctx* ctx, const char* what, const char* detail);
 
 // engine_core.hip
 void* dalloc(sam2mi_ctx* ctx, size_t bytes);
+void* dalloc_raw(sam2mi_ctx* ctx, size_t bytes);       // not cleared; may be released with dfree before sam2mi_destroy
+void dfree(sam2mi_ctx* ctx, void* p);
 int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p);                 // with profiling
 int run_rowln(sam2mi_ctx* ctx, hipStream_t s, const RowLnParams& p);               // gemm_rowln.hip, with profiling
 int run_projln(sam2mi_ctx* ctx, hipStream_t s, const ProjLnParams& p);             // gemm_projln.hip, with profiling

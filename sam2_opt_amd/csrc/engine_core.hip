@@ -6,11 +6,13 @@
 
 #include "engine.h"
 
-static std::string g_create_error;
+// Error text is per THREAD (errno-style): one context may be driven from several host threads (encoder and tracking domains run
+// concurrently by design), and the thread whose call returned != 0 is the one that asks for the message.
+static thread_local std::string t_last_error;
 
 int sam2mi_set_error(sam2mi_ctx* ctx, const char* what, const char* detail) {
-  std::string m = std::string(what) + ": " + detail;
-  if (ctx) ctx->err = m; else g_create_error = m;
+  (void)ctx;
+  t_last_error = std::string(what) + ": " + detail;
   return 1;
 }
 
@@ -19,8 +21,27 @@ void* dalloc(sam2mi_ctx* ctx, size_t bytes) {
   if (bytes == 0) bytes = 16;
   if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
   hipMemset(p, 0, bytes);     // finite contents everywhere (pad regions are read by MFMA tiles)
+  std::lock_guard<std::mutex> lk(ctx->misc_mu);      // run-time allocations (resize.hip) may come from two domains at once
   ctx->allocs.push_back(p);
   return p;
+}
+
+// run-time allocations (resize.hip): no clearing pass, releasable before sam2mi_destroy
+void* dalloc_raw(sam2mi_ctx* ctx, size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0) bytes = 16;
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(ctx->misc_mu);
+  ctx->allocs.push_back(p);
+  return p;
+}
+void dfree(sam2mi_ctx* ctx, void* p) {
+  {
+    std::lock_guard<std::mutex> lk(ctx->misc_mu);
+    for (size_t i = 0; i < ctx->allocs.size(); ++i)
+      if (ctx->allocs[i] == p) { ctx->allocs[i] = ctx->allocs.back(); ctx->allocs.pop_back(); break; }
+  }
+  hipFree(p);          // waits for the device: nothing still reads the buffer
 }
 
 template <typename T>
@@ -42,7 +63,10 @@ static void prof_drain(ProfAcc& a) {          // synchronises; profiling mode on
   }
   a.pending.clear();
 }
+// The accumulators are shared by the encoder and the tracking domain (two host threads may profile at once): every access
+// below holds ctx->prof_mu.  prof_begin .. prof_end* of one launch are two short critical sections, not one.
 static void prof_begin(sam2mi_ctx* ctx, ProfAcc& a, hipStream_t s, hipEvent_t& e0, hipEvent_t& e1) {
+  std::lock_guard<std::mutex> lk(ctx->prof_mu);
   if (a.pool.empty()) {
     // drain pending (synchronises; profiling mode only)
     prof_drain(a);
@@ -61,7 +85,8 @@ static void prof_begin(sam2mi_ctx* ctx, ProfAcc& a, hipStream_t s, hipEvent_t& e
   e1 = pr.second;
   hipEventRecord(e0, s);
 }
-static void prof_end(ProfAcc& a, hipStream_t s, hipEvent_t e0, hipEvent_t e1, double flops) {
+static void prof_end(sam2mi_ctx* ctx, ProfAcc& a, hipStream_t s, hipEvent_t e0, hipEvent_t e1, double flops) {
+  std::lock_guard<std::mutex> lk(ctx->prof_mu);
   hipEventRecord(e1, s);
   a.pending.push_back({e0, e1, nullptr});
   a.flops += flops;
@@ -71,6 +96,7 @@ static void prof_end(ProfAcc& a, hipStream_t s, hipEvent_t e0, hipEvent_t e1, do
 // second accumulator keyed by the kernel instantiation: same events, drained together in sam2mi_profile_read_kernels
 static void prof_end_named(sam2mi_ctx* ctx, ProfAcc& a, const std::string& name, hipStream_t s, hipEvent_t e0, hipEvent_t e1, double flops,
                            double bytes = 0) {
+  std::lock_guard<std::mutex> lk(ctx->prof_mu);
   ProfAcc& k = ctx->prof_by_kernel[name];       // std::map: references stay valid
   k.flops += flops;
   k.bytes += bytes;
@@ -85,7 +111,7 @@ static void prof_end_named(sam2mi_ctx* ctx, ProfAcc& a, const std::string& name,
 bool xs_eligible(const sam2mi_ctx* ctx, const GemmParams& p) {
   static const int min_k = getenv("SAM2MI_XS_MINK") ? atoi(getenv("SAM2MI_XS_MINK")) : 0;      // A/B aid
   static const int min_m = getenv("SAM2MI_XS_MINM") ? atoi(getenv("SAM2MI_XS_MINM")) : 16384;      // A/B aid: 8192 takes batch-2 encoder calls from 9.67 to 9.27 ms (batch 1, M = 4096: 6.24 -> 6.39), but then a 2-frame and a 1-frame pass of the same frame differ in the last bits
-  return ctx->use_xs && p.pool_w == 0 && p.K >= min_k && p.xs_pack && p.tile_hint == 0 && p.M >= min_m && (p.ln_x32 ? p.ln_ld == p.K : p.lda == p.K) && gemm_xs_supported(p.N, p.K) &&
+  return ctx->use_xs && !p.a_lo_off && !p.w_lo_off && !p.out_lo_off && p.pool_w == 0 && p.K >= min_k && p.xs_pack && p.tile_hint == 0 && p.M >= min_m && (p.ln_x32 ? p.ln_ld == p.K : p.lda == p.K) && gemm_xs_supported(p.N, p.K) &&
          (p.act == ACT_NONE || p.act == ACT_GELU) && p.rope_cols == 0 && p.res_mod == 0 && !p.outT32 && (p.n_split >= p.N || (p.n_split & 31) == 0) &&
          !(p.out32 && p.out16) && (p.out32 || p.out16) && (!p.res || p.out32) && p.bias &&
          (!p.col_scale || (p.xs_scale_cols > 0 && p.xs_scale_cols <= 576 && (p.xs_scale_cols + 31) / 32 * 32 <= p.n_split));
@@ -112,10 +138,17 @@ static double gemm_algo_bytes(const GemmParams& p) {
 
 int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p_in) {
   GemmParams p = p_in;
-  if (ctx->precise) {            // f16x3: split operands (activations: arena lo plane; weights: packed [hi | lo], or an arena buffer)
-    if (!p.a_lo_off) p.a_lo_off = ctx->lo16;
-    if (!p.w_lo_off) p.w_lo_off = ctx->lo16;
-    p.out_lo_off = (p.out16 || p.outT16) ? ctx->lo16 : 0;
+  if (ctx->precise) {            // split operands (activations: arena lo plane; weights: packed [hi | lo], or an arena buffer)
+    const int prec = (ctx->selective && p.prec != PREC_AUTO) ? p.prec : PREC_FULL;      // f16x3: every linear fully split
+    if (prec == PREC_FULL) {
+      if (!p.a_lo_off) p.a_lo_off = ctx->lo16;
+      if (!p.w_lo_off) p.w_lo_off = ctx->lo16;
+    } else {
+      p.a_lo_off = 0;
+      if (prec == PREC_F16) p.w_lo_off = 0;
+      else if (!p.w_lo_off) p.w_lo_off = ctx->lo16;
+    }
+    p.out_lo_off = ((p.out16 || p.outT16) && !(ctx->selective && p.no_out_lo)) ? ctx->lo16 : 0;
   }
   if (ks_eligible(ctx, p)) {
     GemmKsParams k{p.A, p.lda, p.ks_pack, p.bias, p.res, p.ldres, p.out32, p.ld32, p.M, p.K};
@@ -160,7 +193,7 @@ int run_hiera_attn(sam2mi_ctx* ctx, hipStream_t s, const HieraAttnParams& p) {
   CHK(hiera_attn_launch(p, s));
   // algorithmic flops: 4 * Nq * Nk_visible * 72 per head
   const double nk_vis = (p.wq >= p.GQ) ? p.GK : p.wk;
-  if (ctx->prof_on) prof_end(ctx->prof_attn, s, e0, e1, 4.0 * p.num_groups * (double)p.GQ * nk_vis * 72.0 * p.heads);
+  if (ctx->prof_on) prof_end(ctx, ctx->prof_attn, s, e0, e1, 4.0 * p.num_groups * (double)p.GQ * nk_vis * 72.0 * p.heads);
   return 0;
 }
 int run_precise_attn(sam2mi_ctx* ctx, hipStream_t s, const PreciseAttnParams& p) {
@@ -168,7 +201,7 @@ int run_precise_attn(sam2mi_ctx* ctx, hipStream_t s, const PreciseAttnParams& p)
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_attn, s, e0, e1);
   CHK(precise_attn_launch(p, s));
   const double nk_vis = (p.wq >= p.GQ) ? p.GK : p.wk;
-  if (ctx->prof_on) prof_end(ctx->prof_attn, s, e0, e1, 4.0 * p.num_groups * (double)p.GQ * nk_vis * 72.0 * p.heads);
+  if (ctx->prof_on) prof_end(ctx, ctx->prof_attn, s, e0, e1, 4.0 * p.num_groups * (double)p.GQ * nk_vis * 72.0 * p.heads);
   return 0;
 }
 int run_rowln(sam2mi_ctx* ctx, hipStream_t s, const RowLnParams& p) {
@@ -198,7 +231,7 @@ int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p) {
   hipEvent_t e0, e1;
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_attn, s, e0, e1);
   CHK(flash256_launch(p, s));
-  if (ctx->prof_on) prof_end(ctx->prof_attn, s, e0, e1, 4.0 * p.Nq * (double)p.Nk * 256.0);
+  if (ctx->prof_on) prof_end(ctx, ctx->prof_attn, s, e0, e1, 4.0 * p.Nq * (double)p.Nk * 256.0);
   return 0;
 }
 
@@ -359,16 +392,17 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   if (ctx->cfg.max_batch <= 0) ctx->cfg.max_batch = 1;
   if (ctx->cfg.bank_slots <= 0) ctx->cfg.bank_slots = 64;
   if (ctx->cfg.feat_slots <= 0) ctx->cfg.feat_slots = 16;
-  if (ctx->cfg.precision != SAM2MI_PRECISION_F16 && ctx->cfg.precision != SAM2MI_PRECISION_F16X3) {
-    sam2mi_set_error(nullptr, "sam2mi_create", "unknown precision (0: f16, 1: f16x3)");
+  if (ctx->cfg.precision != SAM2MI_PRECISION_F16 && ctx->cfg.precision != SAM2MI_PRECISION_F16X3 && ctx->cfg.precision != SAM2MI_PRECISION_F16S) {
+    sam2mi_set_error(nullptr, "sam2mi_create", "unknown precision (0: f16, 1: f16x3, 2: f16s)");
     delete ctx;
     return 1;
   }
-  ctx->precise = ctx->cfg.precision == SAM2MI_PRECISION_F16X3;
+  ctx->precise = ctx->cfg.precision != SAM2MI_PRECISION_F16;
+  ctx->selective = ctx->cfg.precision == SAM2MI_PRECISION_F16S;
   // the X-stationary / fused-MLP / accumulator-stationary kernels take plain f16 operands: the f16x3 mode runs every linear
   // on the split-operand instantiation of the tiled kernel (gemm2.hip)
   ctx->use_fused_mlp = !ctx->precise && getenv("SAM2MI_NO_FUSED_MLP") == nullptr;
-  ctx->use_xs = !ctx->precise && getenv("SAM2MI_NO_XS") == nullptr;
+  ctx->use_xs = (!ctx->precise || ctx->selective) && getenv("SAM2MI_NO_XS") == nullptr;      // f16s: the linears planned as plain f16
   ctx->use_rowln = !ctx->precise && getenv("SAM2MI_NO_ROWLN") == nullptr;
   ctx->use_projln = !ctx->precise && getenv("SAM2MI_NO_PROJLN") == nullptr;
   // norm1 inside the operand load of the X-stationary QKV kernel: pays in stage 1 only (C = 144: the QKV launch goes 162 -> 200 us and the
@@ -407,7 +441,7 @@ extern "C" void sam2mi_destroy(sam2mi_ctx* ctx) {
   delete ctx;
 }
 
-extern "C" const char* sam2mi_last_error(sam2mi_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+extern "C" const char* sam2mi_last_error(sam2mi_ctx* ctx) { (void)ctx; return t_last_error.c_str(); }
 
 extern "C" int sam2mi_load_weight(sam2mi_ctx* ctx, const char* key, const float* host_data, const int64_t* shape, int ndim) {
   if (!ctx || !key || !host_data) return sam2mi_set_error(ctx, "sam2mi_load_weight", "null argument");
@@ -424,6 +458,7 @@ extern "C" int sam2mi_load_weight(sam2mi_ctx* ctx, const char* key, const float*
 }
 
 extern "C" int sam2mi_profile_enable(sam2mi_ctx* ctx, int on) {
+  std::lock_guard<std::mutex> lk(ctx->prof_mu);
   ctx->prof_on = on != 0;
   if (on) {
     for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp, &ctx->prof_xs, &ctx->prof_ks}) { a->ms = 0; a->flops = 0; a->launches = 0; }
@@ -434,6 +469,7 @@ extern "C" int sam2mi_profile_enable(sam2mi_ctx* ctx, int on) {
 
 extern "C" int sam2mi_profile_read(sam2mi_ctx* ctx, double* gemm_ms, double* gemm_flops, int64_t* gemm_launches,
                                    double* attn_ms, double* attn_flops, int64_t* attn_launches) {
+  std::lock_guard<std::mutex> lk(ctx->prof_mu);
   for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_attn, &ctx->prof_mlp, &ctx->prof_xs, &ctx->prof_ks}) {
     prof_drain(*a);
   }
@@ -451,6 +487,7 @@ static int prof_read_one(ProfAcc& a, double* ms, double* flops, int64_t* launche
 // Call after sam2mi_profile_read (which drains the events).  Returns the number of bytes written, or -1.
 extern "C" int sam2mi_profile_read_kernels(sam2mi_ctx* ctx, char* out, int cap) {
   if (!ctx || !out || cap <= 0) return -1;
+  std::lock_guard<std::mutex> lk(ctx->prof_mu);
   for (ProfAcc* a : {&ctx->prof_gemm, &ctx->prof_mlp, &ctx->prof_xs, &ctx->prof_ks}) prof_drain(*a);
   std::string sout;
   for (auto& kv : ctx->prof_by_kernel) {
@@ -473,7 +510,7 @@ extern "C" int sam2mi_profile_read_mlp(sam2mi_ctx* ctx, double* ms, double* flop
   return ctx ? prof_read_one(ctx->prof_mlp, ms, flops, launches) : 1;
 }
 static int prof_read_one(ProfAcc& a, double* ms, double* flops, int64_t* launches) {
-  prof_drain(a);
+  prof_drain(a);        // callers: single-threaded read-out after the profiled pass
   if (ms) *ms = a.ms;
   if (flops) *flops = a.flops;
   if (launches) *launches = a.launches;
@@ -534,7 +571,7 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
       b.fc1 = pk.lin16(p + "mlp.layers.0");
       b.fc2 = pk.lin16(p + "mlp.layers.1");
       for (Lin16* L : {&b.qkv, &b.fc1}) {       // stages 1-3: QKV and fc1 also in the X-stationary kernel's piece order (the projection, N = K, is not faster there)
-        if (!pk.ok || ctx->precise || !L->w || !gemm_xs_supported(L->N, L->K) || (L == &b.fc1 && mlp_fused_supported(b.dim_out))) continue;
+        if (!pk.ok || (ctx->precise && !ctx->selective) || !L->w || !gemm_xs_supported(L->N, L->K) || (L == &b.fc1 && mlp_fused_supported(b.dim_out) && !ctx->precise)) continue;
         L->xs_pack = (half_t*)dalloc(ctx, gemm_xs_pack_bytes(L->N, L->K));
         if (!L->xs_pack || gemm_xs_pack(L->w, L->N, L->K, L->K, L->xs_pack, nullptr) != hipSuccess) pk.ok = false;
       }

@@ -12,10 +12,27 @@
 
 static const float LOG2E = 1.4426950408889634f;
 
+// The selective-split plan of the f16s precision mode for one Hiera block (tools/precision_shares.py and
+// tools/precision_plan_video.py are the CPU experiments behind it).  What carries the f16-mode error of the encoder is, in this
+// order: the rounding of WEIGHTS (coherent over all tokens: 4.6x the variance of all activation rounding together), of the
+// attention output that feeds the projection (near-uniform attention makes it coherent inside a window), of q / k; stages 1-2
+// and the attention linears of stage 3 matter, the MLP of stage 3 (2/3 of the encoder's FLOPs) and stage 4 hardly do.
+enum { LIN_QKV, LIN_SC, LIN_PROJ, LIN_FC1, LIN_FC2 };
+static int plan_prec(const sam2mi_ctx* ctx, const HieraBlockW& b, int kind) {
+  if (!ctx->selective) return PREC_AUTO;
+  if (b.dim_out >= 1152) return PREC_F16;                                        // stage 4
+  if (kind == LIN_PROJ || kind == LIN_SC) return PREC_FULL;                      // attention output / transition shortcut: x and W
+  if (b.dim_out >= 576) return kind == LIN_QKV ? PREC_WSPLIT : PREC_F16;         // stage 3: MLP as in the f16 mode
+  return PREC_WSPLIT;                                                            // stages 1-2: every weight
+}
+
 int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, int B, int& H, int& W, int& wcur) {
   const int M = B * H * W;
   const int C = b.dim, Co = b.dim_out;
   float* x = ctx->ws_x;
+  // lo planes of the two LayerNorm outputs: only where a consumer splits its activation operand
+  const size_t ln1_lo = (ctx->selective && !(b.q_pool && plan_prec(ctx, b, LIN_SC) == PREC_FULL)) ? 0 : ctx->lo16;
+  const size_t ln2_lo = (ctx->selective && plan_prec(ctx, b, LIN_FC1) != PREC_FULL) ? 0 : ctx->lo16;
   // 1. LN1 - as a kernel of its own only when the QKV projection cannot normalise its operand rows itself
   GemmParams qkv_p = lin_params(ctx->ws_a16, C, M, b.qkv);
   bool fuse1 = false;
@@ -25,12 +42,13 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
     t.n_split = 2 * Co; t.col_scale = b.qscale; t.xs_scale_cols = Co; t.out16 = ctx->ws_qk16; t.ld16 = 2 * Co; t.outT16 = ctx->ws_vT16; t.ldT16 = M;
     fuse1 = xs_eligible(ctx, t);
   }
-  if (!fuse1) CHK(layernorm_launch(x, C, b.n1.w, b.n1.b, 1e-6f, M, C, ctx->ws_a16, C, nullptr, 0, 0, s, ctx->lo16));
+  if (!fuse1) CHK(layernorm_launch(x, C, b.n1.w, b.n1.b, 1e-6f, M, C, ctx->ws_a16, C, nullptr, 0, 0, s, ln1_lo));
   int Mq = M;
   float* xres = x;           // residual target of the attention projection
   if (b.q_pool) {
     // shortcut = maxpool2x2(proj(LN(x)))   (hieradet.py:139-140)
     GemmParams p = lin_params(ctx->ws_a16, C, M, b.sc);
+    p.prec = plan_prec(ctx, b, LIN_SC);
     Mq = M / 4;
     if (wcur <= 16 && (M & 31) == 0) {            // the pool runs in the GEMM epilogue: the unpooled [M, 2C] f32 tensor never exists
       p.pool_w = wcur; p.out32 = x; p.ld32 = Co;            // x is re-used: LN already consumed it
@@ -48,6 +66,7 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
     p.n_split = 2 * Co;
     p.col_scale = b.qscale;                 // q pre-scaled (f32, before the f16 rounding) for the exp2-domain softmax
     p.xs_scale_cols = Co;                   // k / v columns have scale 1
+    p.prec = plan_prec(ctx, b, LIN_QKV);
     if (ctx->precise) {                     // f16x3 mode: the attention kernel takes f32 q / k / V^T and splits them itself
       p.out32 = ctx->ws_qk32; p.ld32 = 2 * Co;
       p.outT32 = ctx->ws_vT32; p.ldT32 = M;
@@ -117,6 +136,7 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   } else {
     GemmParams p = lin_params(ctx->ws_att16, Co, Mq, b.proj);
     p.res = xres; p.ldres = Co; p.out32 = x; p.ld32 = Co;
+    p.prec = plan_prec(ctx, b, LIN_PROJ);
     CHKI(run_gemm(ctx, s, p));
   }
   if (b.q_pool) { H /= 2; W /= 2; wcur /= 2; }
@@ -128,7 +148,7 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
       CHKI(run_mlp_fused(ctx, s, m, Co));
       return 0;
     }
-    if (!proj_ln) CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s, ctx->lo16));
+    if (!proj_ln) CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s, ln2_lo));
     MlpFusedParams m{ctx->ws_a16, Co, b.mlp_pack, b.fc1.b, b.fc2.b, x, Co, Mq};
     CHKI(run_mlp_fused(ctx, s, m, Co));
     return 0;
@@ -136,18 +156,21 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   {
     GemmParams p = lin_params(ctx->ws_a16, Co, Mq, b.fc1);
     p.act = ACT_GELU; p.out16 = ctx->ws_h16; p.ld16 = 4 * Co;
+    p.prec = plan_prec(ctx, b, LIN_FC1);
+    p.no_out_lo = plan_prec(ctx, b, LIN_FC2) != PREC_FULL;      // the hidden tensor: lo plane only for a consumer that splits it
     bool fuse2 = false;
     if (ctx->ln_fuse && b.fc1.xs_ln_pack) {
       GemmParams t = p;
       t.ln_x32 = x; t.ln_ld = Co; t.ln_eps = 1e-6f; t.xs_pack = b.fc1.xs_ln_pack; t.bias = b.fc1.b_ln;
       if ((fuse2 = xs_eligible(ctx, t))) p = t;
     }
-    if (!fuse2 && !proj_ln) CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s, ctx->lo16));
+    if (!fuse2 && !proj_ln) CHK(layernorm_launch(x, Co, b.n2.w, b.n2.b, 1e-6f, Mq, Co, ctx->ws_a16, Co, nullptr, 0, 0, s, ln2_lo));
     CHKI(run_gemm(ctx, s, p));
   }
   {
     GemmParams p = lin_params(ctx->ws_h16, 4 * Co, Mq, b.fc2);
     p.res = x; p.ldres = Co; p.out32 = x; p.ld32 = Co;
+    p.prec = plan_prec(ctx, b, LIN_FC2);
     CHKI(run_gemm(ctx, s, p));
   }
   return 0;

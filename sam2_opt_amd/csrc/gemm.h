@@ -5,6 +5,7 @@
 #include "common.h"
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
+enum { PREC_AUTO = 0, PREC_F16 = 1, PREC_WSPLIT = 2, PREC_FULL = 3 };
 
 struct GemmParams {
   const half_t* A; int lda;      // [M, lda] f16, lda % 8 == 0
@@ -32,9 +33,14 @@ struct GemmParams {
   const half_t* xs_pack;         // W in the piece order of the X-stationary kernel (gemm_xs.hip), or null
   const half_t* ks_pack;         // W in the piece order of the accumulator-stationary kernel (gemm_ks.hip: N = 576), or null
   int xs_scale_cols;             // col_scale is 1 from this column on (lets the X-stationary kernel keep only the q scale); 0: unknown
-  // split-f16 operands (f16x3 precision mode, common.h): lo arrays at these element offsets behind A / W (both or neither);
-  // out_lo_off != 0: out16 / outT16 are written as hi + lo
+  // split-f16 operands (precision modes, common.h): lo arrays at these element offsets behind A / W.  Both set: full split (3 MFMAs
+  // per product); w_lo_off alone: weight split (2 MFMAs); a_lo_off alone is not a mode.  out_lo_off != 0: out16 / outT16 are
+  // written as hi + lo
   size_t a_lo_off, w_lo_off, out_lo_off;
+  // what the caller asks of engine_core's run_gemm in a split-precision context (ignored by the kernels themselves):
+  // PREC_AUTO = the context's default (f16 / full split), PREC_F16 / PREC_WSPLIT / PREC_FULL = this linear's entry in the
+  // selective plan; no_out_lo: the f16 output feeds a consumer that reads the hi plane only - skip the lo plane
+  int prec, no_out_lo;
   // LayerNorm fused into the operand load of the X-stationary kernel (gemm_xs.h): A is ignored, the operand is the normalised
   // row of ln_x32 [M, K] (ln_ld floats per row); xs_pack / bias must be the LN-folded ones.  X-stationary shapes only.
   const float* ln_x32; int ln_ld; float ln_eps;

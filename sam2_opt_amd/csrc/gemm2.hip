@@ -27,22 +27,28 @@ namespace {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-// SPLIT (the "f16x3" precision mode): both operands arrive as two f16 arrays, hi = f16(v) and lo = f16((v - hi) * 2^11) at
-// p.a_lo_off / p.w_lo_off elements behind the hi array.  A stage holds [A_hi | B_hi | A_lo | B_lo]; every fragment pair
+// SPLIT = 1 (the "f16x3" precision mode): both operands arrive as two f16 arrays, hi = f16(v) and lo = f16((v - hi) * 2^11) at
+// p.a_lo_off / p.w_lo_off elements behind the hi array.  A stage holds [A_hi | B_hi | B_lo | A_lo]; every fragment pair
 // costs three MFMAs: hi*hi into the main accumulator, lo*hi + hi*lo into a second one that is folded in (x 2^-11) before the
 // epilogue.  The dropped lo*lo term is 2^-22 relative; the 2^11 scale keeps the lo parts in the normal f16 range.
+// SPLIT = 2 (weight split, the "f16s" selective mode): only W is split, stage = [A | B_hi | B_lo], two MFMAs per fragment pair
+// (a*b_hi, a*b_lo).  The rounding of a WEIGHT is the same perturbation for every token, so it survives the averaging over
+// tokens (attention, pooling) that the per-token rounding of an activation does not: on the encoder it carries 4.6x the
+// variance of the activation rounding (tools/precision_shares.py) at a third less work than the full split.
 // RS ("register-staged", K % 64 == 0, even piece split, 2 LDS stages): the K tiles do not arrive by LDS-DMA but through two
 // register sets - global -> VGPR loads issued TWO tiles ahead, written to the LDS stage (same lane-linear piece layout, so the
 // fragment reads are unchanged) one tile ahead.  Twice the bytes in flight of the 2-stage DMA ring at the same LDS footprint.
 // MEASURED AND LOST (tools/gemm_bench.py, hints 41-43): 10-20 % slower than the LDS-DMA ring on every K >= 576
 // shape (fc2 of stage 3: 132 us vs 111 us), equal at K = 144 - the extra VGPR -> LDS hop costs more than the deeper prefetch
 // buys, i.e. the loop is not short of bytes in flight.  Only compiled with -DSAM2MI_EXPERIMENTAL.
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT = false, bool RS = false>
-__global__ __launch_bounds__(WM * WN * 64, RS ? 4 : (WM * WN > 8 || SPLIT) ? 1 : 2) void gemm_v2_kernel(const GemmParams p) {
+template <int BM, int BN, int WM, int WN, int STAGES, int SPLIT = 0, bool RS = false>
+__global__ __launch_bounds__(WM * WN * 64, RS ? 4 : (WM * WN > 8 || SPLIT == 1 || (SPLIT == 2 && BN > 64)) ? 1 : 2) void gemm_v2_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, HALF_STAGE = A_BYTES + B_BYTES, STAGE = HALF_STAGE * (SPLIT ? 2 : 1);
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, HALF_STAGE = A_BYTES + B_BYTES;
+  constexpr int STAGE = HALF_STAGE + (SPLIT ? B_BYTES : 0) + (SPLIT == 1 ? A_BYTES : 0);      // [A | B | B_lo | A_lo]
+  constexpr bool ASPLIT = SPLIT == 1;
   constexpr int A_CALLS = BM / 8 / NW, B_CALLS = BN / 8 / NW;     // 1-KiB pieces per wave
   // EVEN: A and B pieces split evenly over the waves.  Otherwise (12-wave 256x192 workgroup) the PA + PB pieces of a K
   // tile are dealt round-robin, piece q = wave + j * NW (A pieces first); STAGES == 2 only (vmcnt is always drained to 0).
@@ -123,14 +129,16 @@ __global__ __launch_bounds__(WM * WN * 64, RS ? 4 : (WM * WN > 8 || SPLIT) ? 1 :
       for (int j = 0; j < B_CALLS; ++j)
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + b_off[j]), (lds_ptr_t)(sbase + A_BYTES + (wave * B_CALLS + j) * 1024), 16, 0, 0);
       if constexpr (SPLIT) {
-        const char* kal = ka + p.a_lo_off * 2;
         const char* kbl = kb + p.w_lo_off * 2;
 #pragma unroll
-        for (int j = 0; j < A_CALLS; ++j)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kal + a_off[j]), (lds_ptr_t)(sbase + HALF_STAGE + (wave * A_CALLS + j) * 1024), 16, 0, 0);
-#pragma unroll
         for (int j = 0; j < B_CALLS; ++j)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbl + b_off[j]), (lds_ptr_t)(sbase + HALF_STAGE + A_BYTES + (wave * B_CALLS + j) * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kbl + b_off[j]), (lds_ptr_t)(sbase + HALF_STAGE + (wave * B_CALLS + j) * 1024), 16, 0, 0);
+      }
+      if constexpr (ASPLIT) {
+        const char* kal = ka + p.a_lo_off * 2;
+#pragma unroll
+        for (int j = 0; j < A_CALLS; ++j)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kal + a_off[j]), (lds_ptr_t)(sbase + HALF_STAGE + B_BYTES + (wave * A_CALLS + j) * 1024), 16, 0, 0);
       }
     } else {
 #pragma unroll
@@ -143,8 +151,8 @@ __global__ __launch_bounds__(WM * WN * 64, RS ? 4 : (WM * WN > 8 || SPLIT) ? 1 :
   };
 
   // ---- K pipeline: STAGES-1 tiles in flight, counted vmcnt + raw barrier (a __syncthreads() would drain the DMA queue)
-  constexpr int NPW = (A_CALLS + B_CALLS) * (SPLIT ? 2 : 1);           // LDS-DMA pieces this wave issues per K tile
-  struct Frag { half8 a[TM]; half8 b[TN]; half8 al[SPLIT ? TM : 1]; half8 bl[SPLIT ? TN : 1]; };
+  constexpr int NPW = A_CALLS + B_CALLS + (SPLIT ? B_CALLS : 0) + (ASPLIT ? A_CALLS : 0);           // LDS-DMA pieces this wave issues per K tile
+  struct Frag { half8 a[TM]; half8 b[TN]; half8 al[ASPLIT ? TM : 1]; half8 bl[SPLIT ? TN : 1]; };
   auto ldfrag = [&](const char* sA, const char* sB, int s) {
     Frag f;
 #pragma unroll
@@ -152,14 +160,14 @@ __global__ __launch_bounds__(WM * WN * 64, RS ? 4 : (WM * WN > 8 || SPLIT) ? 1 :
       const int row = wm * WTM + i * 32 + fr;
       const int off = row * 128 + (((2 * s + fh) ^ ((row >> 1) & 7)) << 4);
       f.a[i] = *reinterpret_cast<const half8*>(sA + off);
-      if constexpr (SPLIT) f.al[i] = *reinterpret_cast<const half8*>(sA + HALF_STAGE + off);
+      if constexpr (ASPLIT) f.al[i] = *reinterpret_cast<const half8*>(sA + HALF_STAGE + B_BYTES + off);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int row = wn * WTN + j * 32 + fr;
       const int off = row * 128 + (((2 * s + fh) ^ ((row >> 1) & 7)) << 4);
       f.b[j] = *reinterpret_cast<const half8*>(sB + off);
-      if constexpr (SPLIT) f.bl[j] = *reinterpret_cast<const half8*>(sB + HALF_STAGE + off);
+      if constexpr (SPLIT) f.bl[j] = *reinterpret_cast<const half8*>(sB + B_BYTES + off);
     }
     return f;
   };
@@ -169,10 +177,8 @@ __global__ __launch_bounds__(WM * WN * 64, RS ? 4 : (WM * WN > 8 || SPLIT) ? 1 :
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         acc[i][j] = mfma32(f.a[i], f.b[j], acc[i][j]);
-        if constexpr (SPLIT) {
-          accx[i][j] = mfma32(f.al[i], f.b[j], accx[i][j]);
-          accx[i][j] = mfma32(f.a[i], f.bl[j], accx[i][j]);
-        }
+        if constexpr (ASPLIT) accx[i][j] = mfma32(f.al[i], f.b[j], accx[i][j]);
+        if constexpr (SPLIT) accx[i][j] = mfma32(f.a[i], f.bl[j], accx[i][j]);
       }
   };
   auto sync_tile = [&](int kt) {                   // tile kt landed & visible; slot of tile kt-1 free; keep the ring full
@@ -430,17 +436,17 @@ __global__ __launch_bounds__(WM * WN * 64, RS ? 4 : (WM * WN > 8 || SPLIT) ? 1 :
   }
 }
 
-template <int BM, int BN, int STAGES, bool SPLIT = false>
-constexpr size_t v2_smem() { return (size_t)STAGES * (BM + BN) * 128 * (SPLIT ? 2 : 1); }
+template <int BM, int BN, int STAGES, int SPLIT = 0>
+constexpr size_t v2_smem() { return (size_t)STAGES * ((BM + BN) * 128 + (SPLIT ? BN * 128 : 0) + (SPLIT == 1 ? BM * 128 : 0)); }
 
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT = false, bool RS = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int SPLIT = 0, bool RS = false>
 hipError_t v2_launch(const GemmParams& p, hipStream_t s) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const size_t smem = v2_smem<BM, BN, STAGES, SPLIT>();
   gemm_v2_kernel<BM, BN, WM, WN, STAGES, SPLIT, RS><<<dim3(tiles), dim3(WM * WN * 64), smem, s>>>(p);
   return hipGetLastError();
 }
-template <int BM, int BN, int WM, int WN, int STAGES, bool SPLIT = false, bool RS = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int SPLIT = 0, bool RS = false>
 hipError_t v2_attr() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_v2_kernel<BM, BN, WM, WN, STAGES, SPLIT, RS>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_smem<BM, BN, STAGES, SPLIT>());
@@ -450,9 +456,10 @@ hipError_t v2_attr() {
 hipError_t gemm_v2_init() {
   const hipError_t e[] = {
       v2_attr<128, 192, 4, 2, 2>(), v2_attr<128, 128, 4, 2, 2>(), v2_attr<128, 64, 4, 2, 2>(), v2_attr<64, 64, 2, 2, 2>(), v2_attr<64, 64, 2, 2, 4>(),
-      v2_attr<128, 128, 4, 2, 2, true>(), v2_attr<128, 64, 4, 2, 2, true>(), v2_attr<64, 64, 2, 2, 2, true>(),
+      v2_attr<128, 128, 4, 2, 2, 1>(), v2_attr<128, 64, 4, 2, 2, 1>(), v2_attr<64, 64, 2, 2, 2, 1>(),
+      v2_attr<128, 128, 4, 2, 2, 2>(), v2_attr<128, 64, 4, 2, 2, 2>(), v2_attr<64, 64, 2, 2, 2, 2>(), v2_attr<128, 192, 4, 2, 2, 2>(),
 #ifdef SAM2MI_EXPERIMENTAL
-      v2_attr<128, 192, 4, 2, 2, false, true>(), v2_attr<128, 128, 4, 2, 2, false, true>(), v2_attr<128, 64, 4, 2, 2, false, true>(),
+      v2_attr<128, 192, 4, 2, 2, 0, true>(), v2_attr<128, 128, 4, 2, 2, 0, true>(), v2_attr<128, 64, 4, 2, 2, 0, true>(),
       v2_attr<256, 192, 4, 2, 2>(), v2_attr<256, 256, 4, 4, 2>(), v2_attr<256, 192, 4, 3, 2>(), v2_attr<256, 128, 4, 2, 3>(), v2_attr<128, 128, 2, 2, 2>(),
       v2_attr<128, 64, 2, 2, 2>(), v2_attr<128, 64, 2, 2, 3>(), v2_attr<128, 128, 2, 2, 3>(), v2_attr<256, 128, 4, 2, 2>(),
       v2_attr<256, 64, 4, 2, 2>(),
@@ -480,13 +487,23 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   if (p.rope_cols > 0 && (p.rope_cols > p.n_split || (p.rope_cols & 3) || (p.rope_dim & 3) || (p.N & 3) || (p.ld32 & 3) || (p.ld16 & 3) ||
                           (p.ldres & 3) || p.rope_len <= 0))
     return hipErrorInvalidValue;                          // RoPE runs on the row-major 4-column phase of the epilogue
-  if (p.a_lo_off || p.w_lo_off) {                        // split-f16 operands (f16x3 precision mode)
-    if (!p.a_lo_off || !p.w_lo_off) return hipErrorInvalidValue;
+  if (p.a_lo_off) {                                      // split-f16 operands (f16x3 precision mode)
+    if (!p.w_lo_off) return hipErrorInvalidValue;
     switch (gemm_v2_auto_tile(p)) {
       case 3:
-      case 2: return v2_launch<128, 128, 4, 2, 2, true>(p, s);
-      case 1: return v2_launch<128, 64, 4, 2, 2, true>(p, s);
-      default: return v2_launch<64, 64, 2, 2, 2, true>(p, s);
+      case 2: return v2_launch<128, 128, 4, 2, 2, 1>(p, s);
+      case 1: return v2_launch<128, 64, 4, 2, 2, 1>(p, s);
+      default: return v2_launch<64, 64, 2, 2, 2, 1>(p, s);
+    }
+  }
+  if (p.w_lo_off) {                                      // weight split only (selective mode)
+    int t = gemm_v2_auto_tile(p);
+    if (p.tile_hint == 16) t = 3; else if (p.tile_hint == 10) t = 2; else if (p.tile_hint == 13) t = 1; else if (p.tile_hint == 5) t = 0;
+    switch (t) {
+      case 3: return v2_launch<128, 192, 4, 2, 2, 2>(p, s);
+      case 2: return v2_launch<128, 128, 4, 2, 2, 2>(p, s);
+      case 1: return v2_launch<128, 64, 4, 2, 2, 2>(p, s);
+      default: return v2_launch<64, 64, 2, 2, 2, 2>(p, s);
     }
   }
 #ifdef SAM2MI_EXPERIMENTAL
@@ -505,9 +522,9 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   if (force == 4) return v2_launch<128, 64, 2, 2, 2>(p, s);
   // register-staged variants (hints 41..43): K % 64 == 0 only
   if (force >= 41 && force <= 43 && (p.K & 63) == 0) {
-    if (force == 43) return v2_launch<128, 192, 4, 2, 2, false, true>(p, s);
-    if (force == 42) return v2_launch<128, 128, 4, 2, 2, false, true>(p, s);
-    return v2_launch<128, 64, 4, 2, 2, false, true>(p, s);
+    if (force == 43) return v2_launch<128, 192, 4, 2, 2, 0, true>(p, s);
+    if (force == 42) return v2_launch<128, 128, 4, 2, 2, 0, true>(p, s);
+    return v2_launch<128, 64, 4, 2, 2, 0, true>(p, s);
   }
 #endif
   int tile = gemm_v2_auto_tile(p);
@@ -551,12 +568,15 @@ int gemm_v2_auto_tile(const GemmParams& p) {
 
 // kernel name as rocprofv3 prints it (profiling by instantiation)
 const char* gemm_v2_kernel_name(const GemmParams& p) {
-  if (p.tile_hint != 0) return "gemm_v2_kernel<forced tile>";
-  static const char* names[5] = {"gemm_v2_kernel<64, 64, 2, 2, 2, false, false>", "gemm_v2_kernel<128, 64, 4, 2, 2, false, false>",
-                                 "gemm_v2_kernel<128, 128, 4, 2, 2, false, false>", "gemm_v2_kernel<128, 192, 4, 2, 2, false, false>",
-                                 "gemm_v2_kernel<64, 64, 2, 2, 4, false, false>"};
-  static const char* split_names[5] = {"gemm_v2_kernel<64, 64, 2, 2, 2, true, false>", "gemm_v2_kernel<128, 64, 4, 2, 2, true, false>",
-                                       "gemm_v2_kernel<128, 128, 4, 2, 2, true, false>", "gemm_v2_kernel<128, 128, 4, 2, 2, true, false>",
-                                       "gemm_v2_kernel<64, 64, 2, 2, 2, true, false>"};
-  return (p.a_lo_off ? split_names : names)[gemm_v2_auto_tile(p)];
+  if (p.tile_hint != 0 && !p.w_lo_off) return "gemm_v2_kernel<forced tile>";
+  static const char* names[5] = {"gemm_v2_kernel<64, 64, 2, 2, 2, 0, false>", "gemm_v2_kernel<128, 64, 4, 2, 2, 0, false>",
+                                 "gemm_v2_kernel<128, 128, 4, 2, 2, 0, false>", "gemm_v2_kernel<128, 192, 4, 2, 2, 0, false>",
+                                 "gemm_v2_kernel<64, 64, 2, 2, 4, 0, false>"};
+  static const char* split_names[5] = {"gemm_v2_kernel<64, 64, 2, 2, 2, 1, false>", "gemm_v2_kernel<128, 64, 4, 2, 2, 1, false>",
+                                       "gemm_v2_kernel<128, 128, 4, 2, 2, 1, false>", "gemm_v2_kernel<128, 128, 4, 2, 2, 1, false>",
+                                       "gemm_v2_kernel<64, 64, 2, 2, 2, 1, false>"};
+  static const char* wsplit_names[5] = {"gemm_v2_kernel<64, 64, 2, 2, 2, 2, false>", "gemm_v2_kernel<128, 64, 4, 2, 2, 2, false>",
+                                        "gemm_v2_kernel<128, 128, 4, 2, 2, 2, false>", "gemm_v2_kernel<128, 192, 4, 2, 2, 2, false>",
+                                        "gemm_v2_kernel<64, 64, 2, 2, 2, 2, false>"};
+  return (p.a_lo_off ? split_names : p.w_lo_off ? wsplit_names : names)[gemm_v2_auto_tile(p)];
 }

@@ -140,36 +140,46 @@ __global__ void aa_v_kernel(const float* __restrict__ tmp, int H, float* __restr
 }
 }  // namespace
 
-// cached device tables for one (kind, in, out) triple
-static int resize_table(sam2mi_ctx* ctx, int kind, int in_size, int out_size, const ResizeTable** out) {
+// cached device tables for one (kind, in, out) triple.  First use of a size triple allocates (hipMalloc: may synchronise the
+// device once) and uploads the tables with hipMemcpyAsync on the CALLER's stream from host vectors the table keeps alive, so the
+// launching thread is not parked behind work queued on other streams; later calls only launch kernels (sam2mi.h).
+static int resize_table(sam2mi_ctx* ctx, hipStream_t s, int kind, int in_size, int out_size, const ResizeTable** out) {
   const uint64_t key = ((uint64_t)kind << 60) | ((uint64_t)in_size << 30) | (uint64_t)out_size;
   auto it = ctx->resize_tables.find(key);
   if (it == ctx->resize_tables.end()) {
-    ResizeTable t;
-    std::vector<int> bounds;
+    it = ctx->resize_tables.emplace(key, ResizeTable()).first;
+    ResizeTable& t = it->second;
     if (kind == 0) {
       std::vector<int> kk;
-      pil_coeffs(in_size, out_size, bounds, kk, t.ksize);
-      t.coef = dalloc(ctx, kk.size() * sizeof(int));
-      if (t.coef) CHK(hipMemcpy(t.coef, kk.data(), kk.size() * sizeof(int), hipMemcpyHostToDevice));
+      pil_coeffs(in_size, out_size, t.h_bounds, kk, t.ksize);
+      t.h_coef.resize(kk.size() * sizeof(int));
+      memcpy(t.h_coef.data(), kk.data(), t.h_coef.size());
     } else {
       std::vector<float> wt;
-      aa_coeffs(in_size, out_size, bounds, wt, t.ksize);
-      t.coef = dalloc(ctx, wt.size() * sizeof(float));
-      if (t.coef) CHK(hipMemcpy(t.coef, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+      aa_coeffs(in_size, out_size, t.h_bounds, wt, t.ksize);
+      t.h_coef.resize(wt.size() * sizeof(float));
+      memcpy(t.h_coef.data(), wt.data(), t.h_coef.size());
     }
-    t.bounds = (int*)dalloc(ctx, bounds.size() * sizeof(int));
-    if (!t.coef || !t.bounds) return sam2mi_set_error(ctx, "resize", "hipMalloc failed");
-    CHK(hipMemcpy(t.bounds, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice));
-    it = ctx->resize_tables.emplace(key, t).first;
+    t.coef = dalloc_raw(ctx, t.h_coef.size());
+    t.bounds = (int*)dalloc_raw(ctx, t.h_bounds.size() * sizeof(int));
+    if (!t.coef || !t.bounds) {
+      ctx->resize_tables.erase(it);
+      return sam2mi_set_error(ctx, "resize", "hipMalloc failed");
+    }
+    CHK(hipMemcpyAsync(t.coef, t.h_coef.data(), t.h_coef.size(), hipMemcpyHostToDevice, s));
+    CHK(hipMemcpyAsync(t.bounds, t.h_bounds.data(), t.h_bounds.size() * sizeof(int), hipMemcpyHostToDevice, s));
   }
   *out = &it->second;
   return 0;
 }
 
+// one scratch buffer per context, grown when a larger frame arrives; the old one is released (hipFree waits for the device, so
+// work still reading it has finished) instead of staying allocated until sam2mi_destroy
 static int resize_scratch(sam2mi_ctx* ctx, size_t bytes, void** out) {
-  if (bytes > ctx->resize_tmp_bytes) {                      // grow-only scratch (the old one stays in ctx->allocs until destroy)
-    ctx->resize_tmp = dalloc(ctx, bytes);
+  if (bytes > ctx->resize_tmp_bytes) {
+    if (ctx->resize_tmp) dfree(ctx, ctx->resize_tmp);
+    ctx->resize_tmp_bytes = 0;
+    ctx->resize_tmp = dalloc_raw(ctx, bytes);
     if (!ctx->resize_tmp) return sam2mi_set_error(ctx, "resize", "hipMalloc failed");
     ctx->resize_tmp_bytes = bytes;
   }
@@ -193,8 +203,8 @@ extern "C" int sam2mi_resize_u8_pil_bicubic(sam2mi_ctx* ctx, void* stream, const
     return 0;
   }
   const ResizeTable *tx, *ty;
-  CHKI(resize_table(ctx, 0, W, S, &tx));
-  CHKI(resize_table(ctx, 0, H, S, &ty));
+  CHKI(resize_table(ctx, s, 0, W, S, &tx));
+  CHKI(resize_table(ctx, s, 0, H, S, &ty));
   void* tmp;
   CHKI(resize_scratch(ctx, (size_t)H * S * 3, &tmp));
   // Pillow skips a pass whose size does not change; with equal sizes its coefficients are the identity, so running it is the same
@@ -211,8 +221,8 @@ extern "C" int sam2mi_resize_image_aa_bilinear(sam2mi_ctx* ctx, void* stream, co
   hipStream_t s = (hipStream_t)stream;
   DomainGuard guard_(ctx->dom_enc, s);
   const ResizeTable *tx, *ty;
-  CHKI(resize_table(ctx, 1, W, S, &tx));
-  CHKI(resize_table(ctx, 1, H, S, &ty));
+  CHKI(resize_table(ctx, s, 1, W, S, &tx));
+  CHKI(resize_table(ctx, s, 1, H, S, &ty));
   void* tmp;
   CHKI(resize_scratch(ctx, (size_t)H * S * 3 * sizeof(float), &tmp));
   const size_t n1 = (size_t)H * S * 3, n2 = (size_t)S * S * 3;

@@ -31,7 +31,7 @@ class Sam2miConfig(C.Structure):
 
 
 ABI_VERSION = 2
-PRECISIONS = {"f16": 0, "f16x3": 1}      # SAM2MI_PRECISION_* (include/sam2mi.h)
+PRECISIONS = {"f16": 0, "f16x3": 1, "f16s": 2}      # SAM2MI_PRECISION_* (include/sam2mi.h)
 
 
 class MemSelect(C.Structure):

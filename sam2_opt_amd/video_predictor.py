@@ -114,13 +114,28 @@ class SAM2VideoPredictor:
     # ------------------------------------------------------------------ state
     @torch.inference_mode()
     @_locked
-    def init_state(self, video_path=None, frames: Optional[torch.Tensor] = None, video_height: Optional[int] = None,
-                   video_width: Optional[int] = None, offload_video_to_cpu: bool = False, frames_u8=None, **_unused):
-        """`frames`: float32 (T,3,1024,1024) already /255 and mean/std normalised (what load_video_frames returns),
-        on CPU or GPU; or `frames_u8`: decoded uint8 (T,1024,1024,3) frames (numpy or torch) - normalised on the device
-        inside the patch-embedding gather, bit-identical to the float path at a quarter of the bytes; or `video_path`: a
-        folder of JPEGs (needs PIL; decoded + resized on the host like utils/misc.py:92-101, then the uint8 path)."""
-        if frames is None and frames_u8 is None:
+    def init_state(self, video_path=None, offload_video_to_cpu: bool = False, offload_state_to_cpu: bool = False,
+                   async_loading_frames: bool = False, frames: Optional[torch.Tensor] = None, video_height: Optional[int] = None,
+                   video_width: Optional[int] = None, frames_u8=None):
+        """`video_path`, `offload_video_to_cpu`, `offload_state_to_cpu`, `async_loading_frames`: the reference's arguments, in its
+        order (sam2_video_predictor_official.py:148-154).  `video_path`: a folder of JPEGs (needs PIL; decoded on the host like
+        utils/misc.py:92-101, resized on the device, then the uint8 path).  Keyword-only extras of this build: `frames`: float32
+        (T,3,1024,1024) already /255 and mean/std normalised (what load_video_frames returns), on CPU or GPU; or `frames_u8`:
+        decoded uint8 (T,1024,1024,3) frames (numpy or torch) - normalised on the device inside the patch-embedding gather,
+        bit-identical to the float path at a quarter of the bytes.
+        `offload_state_to_cpu`: the per-frame outputs the state keeps (low-res mask logits, object scores) live in host memory,
+        like the reference's `storage_device` (:180-183); the memory bank itself is a fixed pool of `bank_slots` entries in HBM
+        that recycles on its own, so it is what bounds the device footprint of a long clip, not this option.
+        `async_loading_frames`: JPEGs are decoded by a background thread (utils/misc.py:104-169); frame 0 is decoded before
+        the call returns, a frame that tracking reaches before the thread is decoded on demand."""
+        loader = None
+        if async_loading_frames:
+            if frames is not None or frames_u8 is not None:
+                raise ValueError("async_loading_frames needs video_path (frames passed as tensors are loaded already)")
+            loader = _AsyncJpegFrames(video_path, self, offload_video_to_cpu)
+            frames = loader                                       # len() / shape[0]; frames reach the device batch by batch
+            video_height, video_width = video_height or loader.video_height, video_width or loader.video_width
+        elif frames is None and frames_u8 is None:
             frames_u8 = _load_jpeg_folder(video_path)             # decoded on the host (PIL), resized on the device below
         if frames is None:
             if isinstance(frames_u8, (list, tuple)):               # frames of any size, decoded (H,W,3) uint8 arrays
@@ -132,10 +147,11 @@ class SAM2VideoPredictor:
             if tuple(frames.shape[1:3]) != (self.image_size, self.image_size):
                 video_height, video_width = video_height or frames.shape[1], video_width or frames.shape[2]
                 frames = self._resize_frames(list(frames))
-        if not offload_video_to_cpu:
-            frames = frames.to(self.device)
+        if loader is None:
+            frames = frames.to("cpu" if offload_video_to_cpu else self.device)
         st = {
-            "images": frames, "num_frames": frames.shape[0],
+            "images": frames, "num_frames": len(frames), "loader": loader, "offload_state_to_cpu": bool(offload_state_to_cpu),
+            "storage_device": torch.device("cpu") if offload_state_to_cpu else self.device,
             "video_height": video_height or self.image_size, "video_width": video_width or self.image_size,
             "device": self.device, "offload_video_to_cpu": offload_video_to_cpu,
             "point_inputs_per_obj": {}, "mask_inputs_per_obj": {}, "obj_id_to_idx": OrderedDict(), "obj_idx_to_id": OrderedDict(), "obj_ids": [],
@@ -149,6 +165,11 @@ class SAM2VideoPredictor:
         self._sync_encoder_stream()
         self._ensure_features(st, 0, forward=True)       # warm up the backbone like the reference (:204)
         return st
+
+    def _stored(self, st, t):
+        """A per-frame output as the state keeps it: on the host with offload_state_to_cpu (the reference's `storage_device`,
+        sam2_video_predictor_official.py:180-183,:880-897), else where it is."""
+        return t.to("cpu") if st["offload_state_to_cpu"] else t
 
     def _resize_frames(self, frames):
         """load_video_frames_from_jpg_images' PIL resize (utils/misc.py:92-101) on the device: bit-exact bicubic, frame by frame."""
@@ -248,8 +269,20 @@ class SAM2VideoPredictor:
         main = torch.cuda.current_stream(self.device)
         st["stream"] = main
         foreign = set()                                         # streams of OTHER states whose cached frames get evicted
-        while len(self._free_feat_slots) < len(idxs):          # evict the oldest cached frames (of any state; first in, first out)
-            key_old = next(k for k in self._feat_lru if k != (id(st), keep))       # never the frame the caller is about to use
+        # frames the tracking head still needs: the one in use and the rest of its batch in the tracking direction
+        head = start if keep is None else keep
+        in_use = {(id(st), t) for t in range(head, head + step * self.encode_batch, step)} | {(id(st), t) for t in idxs}
+        while len(self._free_feat_slots) < len(idxs):
+            # evict (a) this state's cached frame farthest BEHIND the head in the tracking direction (a pass never returns to it;
+            # after a direction change these are the frames of the old pass's far end, not the ones about to be tracked),
+            # else (b) the least recently USED frame of any state that is not in use (hits refresh the order, _ensure_features)
+            behind = [t for t in m if (t - head) * step < 0 and (id(st), t) not in in_use]
+            if behind:
+                key_old = (id(st), max(behind, key=lambda t: abs(t - head)))
+            else:
+                key_old = next((k for k in self._feat_lru if k not in in_use), None)
+                if key_old is None:
+                    raise RuntimeError("feature cache too small for encode_batch (every cached frame is in use)")
             st_old = self._feat_lru.pop(key_old)
             t_old = key_old[1]
             self._free_feat_slots.append(st_old["feat_slot_of_frame"].pop(t_old))
@@ -262,7 +295,9 @@ class SAM2VideoPredictor:
             # consecutive frames (the usual case) are a view of the clip: no gather, and no host-blocking upload of an index tensor
             # (which, queued behind the previous batch on the encoder stream, stalled the launching thread for a whole batch)
             lo, hi = min(idxs), max(idxs)
-            if hi - lo + 1 == len(idxs):
+            if st.get("loader") is not None:                      # async_loading_frames: decoded (on demand) + resized on this stream
+                imgs = st["loader"].get(idxs)
+            elif hi - lo + 1 == len(idxs):
                 imgs = st["images"][lo:hi + 1] if forward else st["images"][lo:hi + 1].flip(0)
             else:
                 imgs = st["images"][idxs]
@@ -296,6 +331,8 @@ class SAM2VideoPredictor:
         m = st["feat_slot_of_frame"]
         if frame_idx not in m:
             self._encode_batch(st, frame_idx, forward, side=False)
+        else:
+            self._feat_lru.move_to_end((id(st), frame_idx))      # a hit refreshes the frame: eviction is least recently USED
         ev = st["feat_events"].pop(frame_idx, None)
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
@@ -354,7 +391,7 @@ class SAM2VideoPredictor:
         od, td = st["output_dict_per_obj"][obj_idx], st["temp_output_dict_per_obj"][obj_idx]
         # the previous prediction on this frame, if any, goes in as a mask prompt (clamped; :352-366)
         prev = td[key].get(frame_idx) or od["cond_frame_outputs"].get(frame_idx) or od["non_cond_frame_outputs"].get(frame_idx)
-        prev_logits = torch.clamp(prev["pred_masks"], -32.0, 32.0).contiguous() if prev is not None else None
+        prev_logits = torch.clamp(prev["pred_masks"].to(self.device), -32.0, 32.0).contiguous() if prev is not None else None
         feat = self._ensure_features(st, frame_idx)
         sel = None if is_init else self._select_memory(od, frame_idx, st["num_frames"], tracked["reverse"])    # may raise: before any slot is taken
         slot = self._alloc_bank(st, protect=() if sel is None else _sel_slots(sel))
@@ -369,7 +406,7 @@ class SAM2VideoPredictor:
         else:
             self.engine.video_track(feat, sel, slot, False, outs, points=pts, labels=lab, multimask=multimask, mask_logits=prev_logits)
         self._free_bank(st, td[key].pop(frame_idx, None))
-        td[key][frame_idx] = dict(slot=slot, pred_masks=low, object_score_logits=score, has_mem=False, is_pts=True)
+        td[key][frame_idx] = dict(slot=slot, pred_masks=self._stored(st, low), object_score_logits=self._stored(st, score), has_mem=False, is_pts=True)
         return frame_idx, st["obj_ids"], self._video_res(st, self._consolidated(st, frame_idx))
 
     def add_new_points(self, *a, **k):
@@ -401,7 +438,7 @@ class SAM2VideoPredictor:
         score = self.engine.new(1, 1)
         self.engine.video_mask(feat, m, slot, dict(low_res_masks=low, object_score_logits=score))
         self._free_bank(st, td[key].pop(frame_idx, None))
-        td[key][frame_idx] = dict(slot=slot, pred_masks=low, object_score_logits=score, has_mem=False, is_pts=False)
+        td[key][frame_idx] = dict(slot=slot, pred_masks=self._stored(st, low), object_score_logits=self._stored(st, score), has_mem=False, is_pts=False)
         return frame_idx, st["obj_ids"], self._video_res(st, self._consolidated(st, frame_idx))
 
     @torch.inference_mode()
@@ -470,7 +507,7 @@ class SAM2VideoPredictor:
             for d in (st["temp_output_dict_per_obj"][obj_idx], st["output_dict_per_obj"][obj_idx]):
                 for k in ("cond_frame_outputs", "non_cond_frame_outputs"):
                     out = out or d[k].get(frame_idx)
-            outs.append(out["pred_masks"] if out is not None else torch.full((1, 1, 256, 256), -1024.0, device=self.device))
+            outs.append(out["pred_masks"].to(self.device) if out is not None else torch.full((1, 1, 256, 256), -1024.0, device=self.device))
         return torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
 
     def _video_res(self, st, low):
@@ -556,7 +593,10 @@ class SAM2VideoPredictor:
         """Non-conditioning outputs that no later frame of THIS pass can attend to become candidates for recycling.  Like the
         reference they keep their memory (a reverse pass or a correction click far behind the tracking head needs it);
         `_alloc_bank` takes their slots back, oldest first, only once the bank is full."""
-        horizon = self.max_obj_ptrs_in_encoder + 1
+        # reach of select_memory: object pointers go back max_obj_ptrs_in_encoder frames, spatial memories (num_maskmem - 2) * r + 1
+        # frames with memory_temporal_stride_for_eval = r (sam2_base_official.py:851-868: ((t - 2) // r) * r - (t_rel - 2) * r)
+        r = max(1, self.memory_temporal_stride_for_eval)
+        horizon = max(self.max_obj_ptrs_in_encoder, (self.num_maskmem - 2) * r + 1) + 1
         t = frame_idx + horizon + 1 if reverse else frame_idx - horizon - 1
         out = od["non_cond_frame_outputs"].get(t)
         if out is not None and out.get("slot") is not None:
@@ -585,7 +625,7 @@ class SAM2VideoPredictor:
                 for obj_idx in range(len(st["obj_ids"])):
                     od = st["output_dict_per_obj"][obj_idx]
                     if frame_idx in od["cond_frame_outputs"]:
-                        per_obj[obj_idx] = od["cond_frame_outputs"][frame_idx]["pred_masks"]
+                        per_obj[obj_idx] = od["cond_frame_outputs"][frame_idx]["pred_masks"].to(self.device)
                         if self.clear_non_cond_mem_around_input:
                             self._clear_obj_non_cond_mem_around_input(st, frame_idx, obj_idx)
                     else:
@@ -614,8 +654,9 @@ class SAM2VideoPredictor:
                         self.engine.video_track_batch(feat, sels, slots, True, outs_l)
                     for obj_idx, slot, outs in zip(chunk, slots, outs_l):
                         od = st["output_dict_per_obj"][obj_idx]
-                        od["non_cond_frame_outputs"][frame_idx] = dict(slot=slot, pred_masks=outs["low_res_masks"],
-                                                                       object_score_logits=outs["object_score_logits"], has_mem=True, is_pts=False)
+                        od["non_cond_frame_outputs"][frame_idx] = dict(slot=slot, pred_masks=self._stored(st, outs["low_res_masks"]),
+                                                                       object_score_logits=self._stored(st, outs["object_score_logits"]),
+                                                                       has_mem=True, is_pts=False)
                         self._release_stale(st, obj_idx, od, frame_idx, reverse)
                         per_obj[obj_idx] = outs["low_res_masks"]
                 if todo and not _PREFETCH_EARLY:
@@ -631,16 +672,72 @@ def _sel_slots(sel: MemSelect):
     return {sel.mem_slot[i] for i in range(sel.num_mem)} | {sel.ptr_slot[i] for i in range(sel.num_ptr)}
 
 
-def _load_jpeg_folder(path):
-    """The decode half of load_video_frames_from_jpg_images (utils/misc.py:213-277): JPEGs named <frame index>.jpg, sorted by
-    that index, decoded to RGB uint8 by PIL.  Returns a list of (H,W,3) arrays at the video's own resolution."""
-    import os
-
-    from PIL import Image
+def _jpeg_paths(path):
+    """Frame files of a JPEG folder in the reference's order (utils/misc.py:246-255): <frame index>.jpg, sorted by that index."""
     if not isinstance(path, str) or not os.path.isdir(path):
         raise NotImplementedError("Only JPEG frames are supported at this moment (pass a folder of <frame index>.jpg files)")
     names = sorted([p for p in os.listdir(path) if os.path.splitext(p)[-1].lower() in (".jpg", ".jpeg")],
                    key=lambda p: int(os.path.splitext(p)[0]))
     if not names:
         raise RuntimeError(f"no images found in {path}")
-    return [np.array(Image.open(os.path.join(path, n)).convert("RGB")) for n in names]
+    return [os.path.join(path, n) for n in names]
+
+
+def _decode_jpeg(path):
+    from PIL import Image
+    return np.array(Image.open(path).convert("RGB"))
+
+
+def _load_jpeg_folder(path):
+    """The decode half of load_video_frames_from_jpg_images (utils/misc.py:213-277): decoded to RGB uint8 by PIL.  Returns a
+    list of (H,W,3) arrays at the video's own resolution."""
+    return [_decode_jpeg(p) for p in _jpeg_paths(path)]
+
+
+class _AsyncJpegFrames:
+    """`async_loading_frames=True`: the reference's AsyncVideoFrameLoader (utils/misc.py:104-169).  Frame 0 is decoded in the
+    constructor (it fixes the video size and is where the first click usually lands), a daemon thread decodes the others in
+    order; a frame requested before the thread reached it is decoded by the caller, and an exception of the thread is re-raised
+    on the next request.  The thread only DECODES (host work); the bit-exact bicubic resize runs on the device, on the stream of
+    the encoder pass that asks for the frames (`get`), so no GPU work is ever issued from the background thread."""
+
+    def __init__(self, video_path, predictor, offload_video_to_cpu):
+        self.paths = _jpeg_paths(video_path)
+        self.predictor = predictor
+        self.offload = bool(offload_video_to_cpu)
+        self.host = [None] * len(self.paths)            # decoded (H,W,3) uint8 arrays at the video's resolution
+        self.resized = {}                               # frame -> (S,S,3) uint8 tensor (device, or host with offload_video_to_cpu)
+        self.exception = None
+        first = self._decoded(0)
+        self.video_height, self.video_width = first.shape[0], first.shape[1]
+
+        def _load_frames():
+            try:
+                for n in range(len(self.paths)):
+                    self._decoded(n)
+            except Exception as e:                     # surfaced by the next get()
+                self.exception = e
+        self.thread = threading.Thread(target=_load_frames, daemon=True)
+        self.thread.start()
+
+    def __len__(self):
+        return len(self.paths)
+
+    def _decoded(self, i):
+        img = self.host[i]
+        if img is None:
+            img = self.host[i] = _decode_jpeg(self.paths[i])      # a race with the thread decodes a frame twice: harmless, as in the reference
+        return img
+
+    def get(self, idxs):
+        """uint8 (n,S,S,3) device tensor of the frames `idxs`, in that order."""
+        if self.exception is not None:
+            raise RuntimeError("Failure in frame loading thread") from self.exception
+        out = []
+        for t in idxs:
+            r = self.resized.get(t)
+            if r is None:
+                r = self.predictor._resize_frames([self._decoded(t)])[0]
+                self.resized[t] = r.cpu() if self.offload else r
+            out.append(r.to(self.predictor.device))
+        return torch.stack(out)

@@ -99,3 +99,42 @@ def test_jpeg_folder_matches_reference_loader(sd_large, cfg_large, tmp_path):
         assert len(out) == n and tuple(out[0].shape[-2:]) == (st["video_height"], st["video_width"])
     finally:
         pred.release()
+
+
+@pytest.mark.gpu
+def test_init_state_reference_options(sd_large, tmp_path):
+    """init_state(video_path, offload_video_to_cpu, offload_state_to_cpu, async_loading_frames) - the reference's signature
+    (sam2_video_predictor_official.py:148-154): every combination tracks the JPEG clip to the SAME masks as the plain call
+    (bit-equal), async loading decodes in a background thread (utils/misc.py:104-169), offloaded per-frame outputs live on the host."""
+    pytest.importorskip("PIL.Image")
+    from sam2_opt_amd.video_predictor import SAM2VideoPredictor
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ingest_jpeg.npz"))
+    n = int(g["num_frames"][0])
+    for i in range(n):
+        (tmp_path / f"{i:05d}.jpg").write_bytes(g[f"jpeg{i}"].tobytes())
+    pred = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=2)
+    try:
+        outs = {}
+        for name, args in (("plain", ()), ("positional", (True, True, True)), ("async", (False, False, True)), ("offload", (False, True, False))):
+            st = pred.init_state(str(tmp_path), *args)
+            assert st["num_frames"] == n and (st["video_height"], st["video_width"]) == (int(g["video_hw"][0]), int(g["video_hw"][1]))
+            pred.add_new_points_or_box(st, 0, 1, points=np.array([[160.0, 90.0]], np.float32), labels=np.array([1], np.int32))
+            outs[name] = [vm.clone() for _, _, vm in pred.propagate_in_video(st)]
+            assert len(outs[name]) == n
+            stored = st["output_dict_per_obj"][0]["non_cond_frame_outputs"][n - 1]["pred_masks"]
+            assert stored.device.type == ("cpu" if args[1:2] == (True,) else "cuda"), name
+            if args[2:3] == (True,):
+                st["images"].thread.join(timeout=60)
+                assert not st["images"].thread.is_alive() and st["images"].exception is None
+            # a correction click reads the stored (possibly host-resident) logits of the frame
+            pred.add_new_points_or_box(st, n - 1, 1, points=np.array([[100.0, 60.0]], np.float32), labels=np.array([0], np.int32))
+            pred.release_state(st)
+        for name in ("positional", "async", "offload"):
+            for a, b in zip(outs["plain"], outs[name]):
+                assert torch.equal(a, b), name
+        with pytest.raises(ValueError, match="async_loading_frames"):
+            pred.init_state(frames_u8=np.zeros((2, 1024, 1024, 3), np.uint8), async_loading_frames=True)
+        with pytest.raises(TypeError):
+            pred.init_state(str(tmp_path), no_such_option=True)          # unknown options are refused, not swallowed
+    finally:
+        pred.release()

@@ -153,13 +153,17 @@ def test_memory_encoder_precise(eng3, sd_large, cfg_large):
 
 
 # ----------------------------------------------------------------------------- end to end vs the real reference
-def test_video_precise_matches_reference_golden_all_pixels(sd_large, cfg_large):
+@pytest.mark.parametrize("precision,encode_batch,guard", [("f16x3", 4, 1e-4), ("f16s", 4, 9e-4), ("f16s", 8, 9e-4)])
+def test_video_precise_matches_reference_golden_all_pixels(sd_large, cfg_large, precision, encode_batch, guard):
+    """The north-star bar (masks within 1e-3 of the reference's fp32 torch path) on EVERY low-res pixel of the 24-frame golden of
+    the real reference, for both modes of that class: f16x3 (every operand split) and f16s (selective split; encode_batch 8 +
+    encoder prefetch stream = the configuration bench.py times)."""
     from sam2_opt_amd.synthetic import normalize_frames, synthetic_frames_u8
     from sam2_opt_amd.video_predictor import SAM2VideoPredictor
     g = np.load(os.path.join(ROOT, "tests", "golden", "large_video24_full.npz"))
     T = int(g["num_frames"][0])
     frames = normalize_frames(synthetic_frames_u8(seed=2, num_frames=T), cfg_large)
-    pred = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4, precision="f16x3")
+    pred = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=encode_batch, precision=precision, overlap_encode=True)
     try:
         st = pred.init_state(frames=frames, video_height=1024, video_width=1024)
         pred.add_new_points_or_box(st, 0, 1, points=np.array([[512.0, 512.0]], np.float32), labels=np.array([1], np.int32))
@@ -179,14 +183,15 @@ def test_video_precise_matches_reference_golden_all_pixels(sd_large, cfg_large):
                 max_rel = float(max(d.max() - slack, 0.0) / np.abs(ref).max())
                 l2 = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
                 dis = float(((got > 0) != (ref > 0)).mean())
-                print(f"[parity] f16x3 frame {t} {name} ({ref.size} px): max_rel={max_rel:.3e} l2_rel={l2:.3e} sign_disagree={dis:.3e}", flush=True)
+                print(f"[parity] {precision} frame {t} {name} ({ref.size} px): max_rel={max_rel:.3e} l2_rel={l2:.3e} sign_disagree={dis:.3e}", flush=True)
                 worst = dict(max_rel=max(worst["max_rel"], max_rel), l2=max(worst["l2"], l2), dis=max(worst["dis"], dis))
                 if name == "low_res":
                     worst_low = max(worst_low, max_rel, l2)
             n += 1
         assert n == T
-        print(f"[parity] f16x3 video worst over {T} frames, all pixels: {worst}", flush=True)
+        print(f"[parity] {precision} b{encode_batch} video worst over {T} frames, all pixels: {worst}", flush=True)
         assert worst["max_rel"] <= 1e-3 and worst["l2"] <= 1e-3 and worst["dis"] <= 1e-3, worst          # the north-star bar
-        assert worst_low <= 1e-4, worst_low        # regression guard on the f32-stored logits (measured 6e-6 max-abs, 5e-6 rel L2)
+        # regression guard on the f32-stored logits (f16x3 measured 6e-6 max-abs, 5e-6 rel L2; f16s: the plan's own budget)
+        assert worst_low <= guard, worst_low
     finally:
         pred.release()

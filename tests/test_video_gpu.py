@@ -552,3 +552,51 @@ def test_route_a_plug_level_loop_matches_reference_golden(sd_large, cfg_large, p
         assert worst[0] <= tol and worst[1] <= tol and worst[2] <= max(tol, 1e-3), worst
     finally:
         trk.release()
+
+
+def test_temporal_stride_reaches_past_the_pointer_horizon_with_a_full_bank(sd_large):
+    """with memory_temporal_stride_for_eval = 4 the spatial memories reach back (num_maskmem - 2) * 4 + 1 = 21 frames,
+    past the 16-frame object-pointer horizon that alone used to decide which outputs may be recycled.  A bank that is full
+    for most of the clip must still track every frame, to the same masks as a bank that never recycles."""
+    from sam2_opt_amd.synthetic import synthetic_frames_u8
+    from sam2_opt_amd.video_predictor import SAM2VideoPredictor
+    u8 = synthetic_frames_u8(seed=21, num_frames=40)
+    outs = []
+    for slots in (26, 64):
+        p = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4, bank_slots=slots, memory_temporal_stride_for_eval=4)
+        try:
+            st = p.init_state(frames_u8=u8, video_height=1024, video_width=1024)
+            p.add_new_points_or_box(st, 0, 1, points=np.array([CLICK], np.float32), labels=np.array([1], np.int32))
+            outs.append([vm.clone() for _, _, vm in p.propagate_in_video(st)])
+            assert len(outs[-1]) == 40
+        finally:
+            p.release()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_direction_change_keeps_the_frames_about_to_be_tracked_cached(sd_large):
+    """the feature cache evicts the frames farthest BEHIND the tracking head first and refreshes a frame on every hit.
+    After a forward pass, a reverse pass from the last frame must find the frames it starts with still cached (no re-encode of
+    the batch it is about to track), and produce the masks of a predictor whose cache never evicts."""
+    from sam2_opt_amd.synthetic import synthetic_frames_u8
+    from sam2_opt_amd.video_predictor import SAM2VideoPredictor
+    u8 = synthetic_frames_u8(seed=22, num_frames=20)
+    p = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4)            # 8 feature slots
+    try:
+        st = p.init_state(frames_u8=u8, video_height=1024, video_width=1024)
+        p.add_new_points_or_box(st, 10, 1, points=np.array([CLICK], np.float32), labels=np.array([1], np.int32))
+        fwd = [t for t, _, _ in p.propagate_in_video(st)]
+        assert fwd == list(range(10, 20))
+        cached = set(st["feat_slot_of_frame"])
+        assert {16, 17, 18, 19} <= cached, cached               # the head's own batch survived the forward pass
+        calls = []
+        enc = p.engine.video_encode_u8
+        p.engine.video_encode_u8 = lambda imgs, slots: (calls.append(len(slots)), enc(imgs, slots))[1]
+        rev = [(t, vm.clone()) for t, _, vm in p.propagate_in_video(st, start_frame_idx=19, reverse=True, max_frame_num_to_track=3)]
+        assert [t for t, _ in rev] == [19, 18, 17, 16]
+        # frames 19..16 are stored outputs / cached features; only the prefetch of the batch BELOW them may have run
+        assert sum(calls) <= 4, calls
+        assert {16, 17, 18, 19} <= set(st["feat_slot_of_frame"])
+    finally:
+        p.release()
