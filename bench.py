@@ -223,7 +223,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the clip timed on the CPU oracle (steady state = frames 8..)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads of the baseline leg (reported as `cores`)")
-    ap.add_argument("--precision", default="f16", choices=("f16", "f16x3"), help="precision mode of the timed run")
+    ap.add_argument("--precision", default="f16", choices=("f16", "f16x3", "f16s"), help="precision mode of the timed run")
     ap.add_argument("--no-secondary", action="store_true", help="skip the f16x3 / config-5 secondary measurements")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--stub-predictor", action="store_true", help="CPU stand-in predictor (orchestration tests only; never a result)")

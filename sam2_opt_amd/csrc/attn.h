@@ -13,6 +13,9 @@ struct HieraAttnParams {
   int wq, wk;                   // query i sees key j (indices inside the group) iff i / wq == j / wk
   int num_groups;
   float scale_log2e;            // head_dim^-0.5 * log2(e)
+  // selective-split mode (f16s): q and k carry a lo plane qk_lo_off elements behind the hi plane (scores from three products),
+  // the output is written as hi + lo (o_lo_off, 0: hi only).  Stage-3 shapes only (unmasked groups, GQ % 128 == 0).
+  size_t qk_lo_off, o_lo_off;
 };
 hipError_t hiera_attn_launch(const HieraAttnParams& p, hipStream_t stream);
 

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p
 constexpr int H2_NST = 4;
 constexpr int H2_KT = 32 * 144;            // 4608 B
 constexpr int H2_VT = HD * 64;             // 4608 B
-constexpr int H2_STAGE = H2_KT + H2_VT + 64;   // 9280 B: the 64 B behind the V^T image are "row 72" = ones (never touched by the DMA)
+// stage = [K | V^T | ones] (SPLIT: [K_hi | K_lo | V^T | ones]); the 64 B behind the V^T image are "row 72" = ones (never touched by the DMA)
+template <bool SPLIT> constexpr int h2_stage() { return (SPLIT ? 2 : 1) * H2_KT + H2_VT + 64; }      // 9,280 / 13,888 B
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -206,8 +207,17 @@ static __device__ __forceinline__ int h2_pi23(int i) { return (i & ~12) | ((i & 
 template <int N>
 static __device__ __forceinline__ void h2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[H2_NST * H2_STAGE];
+// SPLIT (the selective-split precision mode, f16s): q and k arrive as 2-term f16 splits (hi plane + lo plane qk_lo_off elements
+// behind it, lo = f16((v - hi) * 2^11), common.h) and the scores take three products - K_hi Q_hi^T into the main accumulator,
+// K_lo Q_hi^T + K_hi Q_lo^T into a second one that is folded in x 2^-11 - because the f16 rounding of q and k is what carries
+// the attention's share of the mask error (tools/precision_sim.py: 6.8e-4 of max|ref| against 1.9e-4 for p and v, which stay
+// f16).  The K_lo image rides in the same ring stage; the output is written as hi + lo (o_lo_off) for the split projection.
+template <bool SPLIT>
+__global__ __launch_bounds__(256, SPLIT ? 2 : 3) void hiera_attn_v2_kernel(const HieraAttnParams p) {
+  constexpr int STAGE = h2_stage<SPLIT>();
+  constexpr int VOFF = (SPLIT ? 2 : 1) * H2_KT;        // V^T image inside a stage
+  constexpr int PPT = SPLIT ? 4 : 3;                   // DMA pieces per wave and tile
+  __shared__ __attribute__((aligned(16))) char smem[H2_NST * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, fh = lane >> 5;
@@ -220,48 +230,59 @@ __global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnPa
 
   // ---- Q fragments (B operand): lane holds Q[q = fr][d = 16 s + 8 fh + j]; pre-scaled by 72^-0.5 * log2(e)
   const size_t qrow = (size_t)grp * p.GQ + qt * 32 + fr;
-  half8 qf[5];
+  half8 qf[5], ql[SPLIT ? 5 : 1];
 #pragma unroll
   for (int s = 0; s < 5; ++s) {
     if (s == 4 && fh == 1) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) qf[s][j] = (half_t)0.f;
+      if (SPLIT) ql[SPLIT ? s : 0] = qf[s];
     } else {
-      qf[s] = *reinterpret_cast<const half8*>(p.q + qrow * p.ldq + head * HD + s * 16 + fh * 8);
+      const half_t* qp = p.q + qrow * p.ldq + head * HD + s * 16 + fh * 8;
+      qf[s] = *reinterpret_cast<const half8*>(qp);
+      if (SPLIT) ql[SPLIT ? s : 0] = *reinterpret_cast<const half8*>(qp + p.qk_lo_off);
     }
   }
 
-  // ---- LDS-DMA sources.  288 K chunks + 288 V^T chunks per tile = 4.5 + 4.5 wave-instructions: wave w moves K chunks
-  // [64 w, 64 w + 64), V^T chunks likewise, and a third half-wave piece: chunks 256..287 of K (waves 0, 2) or of V^T
-  // (waves 1, 3) - written twice with identical bytes, so that every wave has exactly 3 pieces per tile in flight.
+  // ---- LDS-DMA sources.  288 chunks per image and tile = 4.5 wave-instructions: wave w moves chunks [64 w, 64 w + 64) of
+  // every image, and one half-wave piece: chunks 256..287 of K (waves 0, 2) or of V^T (waves 1, 3) - written twice with
+  // identical bytes, so that every wave has exactly PPT pieces per tile in flight (SPLIT: K_hi, K_lo, V^T, K_hi again).
   const half_t* kbase = p.k + ((size_t)grp * p.GK) * p.ldk + head * HD;
   const half_t* vbase = p.vT + (size_t)head * HD * p.ldvT + (size_t)grp * p.GK;
   auto k_off = [&](int c) { return (c / 9) * p.ldk + (c % 9) * 8; };                              // halfs from kbase (+ k0 rows)
   auto v_off = [&](int c) { const int d = c >> 2, pc = c & 3; return d * p.ldvT + ((pc ^ ((d >> 2) & 3)) << 3); };
   const int c_main = wave * 64 + lane, c_tail = 256 + (lane & 31);
   const int ko_main = k_off(c_main), vo_main = v_off(c_main);
-  const bool tail_is_k = (wave & 1) == 0;
-  const int o_tail = tail_is_k ? k_off(c_tail) : v_off(c_tail);
+  const int tail_img = SPLIT ? (wave == 3 ? 0 : wave) : (wave & 1);         // SPLIT: 0 K_hi, 1 K_lo, 2 V^T; else 0 K, 1 V^T
+  const bool tail_is_v = tail_img == (SPLIT ? 2 : 1);
+  const size_t o_tail = tail_is_v ? (size_t)v_off(c_tail) : (size_t)k_off(c_tail) + (SPLIT && tail_img == 1 ? p.qk_lo_off : 0);
+  const int tail_dst = tail_img * H2_KT + 4096;
   auto issue = [&](int i) {
-    char* sb = smem + (i % H2_NST) * H2_STAGE;
+    char* sb = smem + (i % H2_NST) * STAGE;
     const half_t* kb = kbase + (size_t)i * 32 * p.ldk;
     const half_t* vb = vbase + i * 32;
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + ko_main), (lds_ptr_t)(sb + wave * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vb + vo_main), (lds_ptr_t)(sb + H2_KT + wave * 1024), 16, 0, 0);
+    if (SPLIT) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + p.qk_lo_off + ko_main), (lds_ptr_t)(sb + H2_KT + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vb + vo_main), (lds_ptr_t)(sb + VOFF + wave * 1024), 16, 0, 0);
     if (lane < 32)
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)((tail_is_k ? kb : vb) + o_tail), (lds_ptr_t)(sb + (tail_is_k ? 0 : H2_KT) + 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)((tail_is_v ? vb : kb) + o_tail), (lds_ptr_t)(sb + tail_dst), 16, 0, 0);
   };
 
   // ---- fragment reads
   const int krow = h2_pi23(fr);
   const int k_base = krow * 144 + fh * 16, k_base4 = krow * 144 + 128;
-  struct KF { half8 f[5]; };
+  struct KF { half8 f[5]; half8 l[SPLIT ? 5 : 1]; };
   auto read_k = [&](int i) {
-    const char* sK = smem + (i % H2_NST) * H2_STAGE;
+    const char* sK = smem + (i % H2_NST) * STAGE;
     KF k;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) k.f[ks] = *reinterpret_cast<const half8*>(sK + k_base + ks * 32);
     k.f[4] = *reinterpret_cast<const half8*>(sK + k_base4);
+    if (SPLIT) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) k.l[SPLIT ? ks : 0] = *reinterpret_cast<const half8*>(sK + H2_KT + k_base + ks * 32);
+      k.l[SPLIT ? 4 : 0] = *reinterpret_cast<const half8*>(sK + H2_KT + k_base4);
+    }
     return k;
   };
   const int vsw = (fr >> 2) & 3;
@@ -269,7 +290,7 @@ __global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnPa
   const int v_sw2 = (v_row2 >> 2) & 3;
   struct VF { half8 f[6]; };
   auto read_v = [&](int i) {
-    const char* sV = smem + (i % H2_NST) * H2_STAGE + H2_KT;
+    const char* sV = smem + (i % H2_NST) * STAGE + VOFF;
     VF v;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -286,6 +307,18 @@ __global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnPa
     for (int r = 0; r < 16; ++r) sa[r] = init;
 #pragma unroll
     for (int ks = 0; ks < 5; ++ks) sa = mfma32(k.f[ks], qf[ks], sa);
+    if (SPLIT) {                   // cross terms in their own chain, folded in x 2^-11 (lo * lo = 2^-22 is dropped)
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        sc = mfma32(k.l[SPLIT ? ks : 0], qf[ks], sc);
+        sc = mfma32(k.f[ks], ql[SPLIT ? ks : 0], sc);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[r] = fmaf(sc[r], SPLIT_INV, sa[r]);
+    }
     return sa;
   };
   auto rowmax = [&](const f32x16& s) {
@@ -303,13 +336,13 @@ __global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnPa
   constexpr float RESCALE_THR = 8.f;
   // ones rows (one per ring stage), before the first barrier
   for (int j = tid; j < H2_NST * 32; j += 256)
-    *reinterpret_cast<half_t*>(smem + (j >> 5) * H2_STAGE + H2_KT + H2_VT + (j & 31) * 2) = (half_t)1.f;
+    *reinterpret_cast<half_t*>(smem + (j >> 5) * STAGE + VOFF + H2_VT + (j & 31) * 2) = (half_t)1.f;
 
   issue(0);
   if (n > 1) issue(1);
   if (n > 2) issue(2);
-  if (n > 2) h2_wait_vm<6>();
-  else if (n > 1) h2_wait_vm<3>();
+  if (n > 2) h2_wait_vm<2 * PPT>();
+  else if (n > 1) h2_wait_vm<PPT>();
   else h2_wait_vm<0>();
   __builtin_amdgcn_s_barrier();
   // scores are kept RELATIVE to the reference maximum: s' = s - m_ref (first tile: subtract its own row maximum)
@@ -341,7 +374,7 @@ __global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnPa
 #pragma nounroll
     for (;;) {
       // tile i+1 landed (tile i+2 may stay in flight); every wave is past tile i-1 -> its ring stage is free
-      if (i + 2 < n) h2_wait_vm<3>();
+      if (i + 2 < n) h2_wait_vm<PPT>();
       else h2_wait_vm<0>();
       __builtin_amdgcn_s_barrier();
       if (i + 3 < n) issue(i + 3);
@@ -375,9 +408,15 @@ __global__ __launch_bounds__(256, 3) void hiera_attn_v2_kernel(const HieraAttnPa
     for (int g = 0; g < 4; ++g) {
       const int d = t * 32 + 8 * g + 4 * fh;
       if (d < HD) {
-        const half4 h = {(half_t)(o[t][4 * g] * inv), (half_t)(o[t][4 * g + 1] * inv),
-                         (half_t)(o[t][4 * g + 2] * inv), (half_t)(o[t][4 * g + 3] * inv)};
+        half4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = o[t][4 * g + e] * inv;
+          h[e] = (half_t)v;
+          if (SPLIT) l[e] = split_lo(v, h[e]);
+        }
         *reinterpret_cast<half4*>(orow + d) = h;
+        if (SPLIT && p.o_lo_off) *reinterpret_cast<half4*>(orow + p.o_lo_off + d) = l;
       }
     }
   }
@@ -395,8 +434,11 @@ hipError_t hiera_attn_launch(const HieraAttnParams& p, hipStream_t stream) {
   const int blocks = (total + 3) / 4;
   const bool mask = !(p.wq >= p.GQ && p.wk >= p.GK);
   static const bool use_v1 = getenv("SAM2MI_HATTN_V1") != nullptr;     // A/B switch: the register-staged kernel
-  if (qtiles % 4 == 0 && !mask && !use_v1 && (p.ldvT & 7) == 0) {
-    hiera_attn_v2_kernel<<<dim3(total / 4), dim3(256), 0, stream>>>(p);
+  if (p.qk_lo_off) {                // split q / k: only the shapes the shared-tile kernel takes (the caller routes the others elsewhere)
+    if (qtiles % 4 || mask || (p.ldvT & 7) || (p.qk_lo_off & 7) || (p.o_lo_off & 3)) return hipErrorInvalidValue;
+    hiera_attn_v2_kernel<true><<<dim3(total / 4), dim3(256), 0, stream>>>(p);
+  } else if (qtiles % 4 == 0 && !mask && !use_v1 && (p.ldvT & 7) == 0) {
+    hiera_attn_v2_kernel<false><<<dim3(total / 4), dim3(256), 0, stream>>>(p);
   } else if (qtiles % 4 == 0) {
     if (mask) hiera_attn_kernel<true, true><<<dim3(blocks), dim3(256), 0, stream>>>(p);
     else hiera_attn_kernel<true, false><<<dim3(blocks), dim3(256), 0, stream>>>(p);

@@ -28,6 +28,7 @@ struct Lin16 {            // MFMA operand: f16 weight [N, K] (nn.Linear layout),
   int N = 0, K = 0;
   size_t lo_off = 0;           // f16x3 mode: the lo plane of w sits lo_off (= N * K) elements behind it; 0 in the f16 mode
   half_t* xs_pack = nullptr;   // same weight in the piece order of the X-stationary GEMM (Hiera stages 1-3, K <= 576)
+  half_t* xs_wpack = nullptr;  // ... as a 2-term split, [W_hi | W_lo] chunk pairs (f16s mode: linears planned as weight split; gemm_xs_wsplit_pack)
   half_t* xs_ln_pack = nullptr;   // ... with the preceding LayerNorm's gain folded in (W diag(g)), for the LN-fused operand load
   float* b_ln = nullptr;          //     and its bias: W b_LN + b
   half_t* ks_pack = nullptr;   // ... of the accumulator-stationary GEMM (N = 576: stage-3 projection and fc2)
@@ -113,6 +114,18 @@ struct ResizeTable {                 // resize.hip: per (kind, in, out) size tri
   std::vector<int> h_bounds; std::vector<char> h_coef;
 };
 
+enum { LIN_QKV = 0, LIN_SC = 1, LIN_PROJ = 2, LIN_FC1 = 3, LIN_FC2 = 4 };     // linear kinds of a Hiera block (f16s plan)
+// linears outside the Hiera blocks, by the forward function that launches them (f16s plan): patch embedding + FPN neck,
+// memory attention, mask decoder (+ prompt encoder), memory encoder.  The running function declares its group with a PlanGroup
+// guard (thread-local: the encoder and the tracking domain may run on two host threads).
+enum { GRP_NECK = 0, GRP_MA = 1, GRP_DEC = 2, GRP_MENC = 3 };
+extern thread_local int tl_plan_group;
+struct PlanGroup {
+  int prev;
+  explicit PlanGroup(int g) : prev(tl_plan_group) { tl_plan_group = g; }
+  ~PlanGroup() { tl_plan_group = prev; }
+};
+
 struct sam2mi_ctx {
   sam2mi_config cfg;
   WsDomain dom_enc, dom_track;
@@ -175,7 +188,13 @@ struct sam2mi_ctx {
   // ---- precision mode (sam2mi_config.precision).  f16x3: every f16 activation buffer below lives in ONE arena whose second
   // half holds the lo planes, so `lo16` (elements) is the hi -> lo distance of all of them; 0 in the default f16 mode.
   bool precise = false;        // f16x3 or f16s: lo planes exist (arena, packed weights)
-  bool selective = false;      // f16s: per-linear plan (GemmParams.prec); everything not planned runs as in f16x3
+  bool selective = false;      // f16s: per-linear plan (GemmParams.prec); everything not planned runs as plan_other
+  // the f16s plan: PREC_* per (Hiera stage 1-4, linear kind LIN_*) and for every linear outside the trunk; split_attn: stage-3 attention on
+  // split q / k (attn_hiera.hip) instead of attn_precise.hip.  Defaults in engine_core.hip (sam2mi_create); SAM2MI_F16S_PLAN overrides
+  // entries for precision experiments ("s3.qkv=f16,s12.all=w,other=f16,attn=0"; tools/f16s_plan_sweep.sh).
+  int plan[5][5] = {};
+  int plan_grp[4] = {3, 3, 3, 3};      // GRP_*: linears outside the Hiera blocks
+  bool split_attn = true;
   size_t lo16 = 0;
   float* ws_qk32 = nullptr;    // f16x3 mode: q|k and V^T of the Hiera blocks in f32 (operands of attn_precise.hip)
   float* ws_vT32 = nullptr;

@@ -111,7 +111,10 @@ static void prof_end_named(sam2mi_ctx* ctx, ProfAcc& a, const std::string& name,
 bool xs_eligible(const sam2mi_ctx* ctx, const GemmParams& p) {
   static const int min_k = getenv("SAM2MI_XS_MINK") ? atoi(getenv("SAM2MI_XS_MINK")) : 0;      // A/B aid
   static const int min_m = getenv("SAM2MI_XS_MINM") ? atoi(getenv("SAM2MI_XS_MINM")) : 16384;      // A/B aid: 8192 takes batch-2 encoder calls from 9.67 to 9.27 ms (batch 1, M = 4096: 6.24 -> 6.39), but then a 2-frame and a 1-frame pass of the same frame differ in the last bits
-  return ctx->use_xs && !p.a_lo_off && !p.w_lo_off && !p.out_lo_off && p.pool_w == 0 && p.K >= min_k && p.xs_pack && p.tile_hint == 0 && p.M >= min_m && (p.ln_x32 ? p.ln_ld == p.K : p.lda == p.K) && gemm_xs_supported(p.N, p.K) &&
+  if (p.w_lo_off) {            // weight split (f16s): the QKV shape only - f16 outputs, no activation, the V^T consumer reads the hi plane
+    if (!p.xs_wpack || p.act != ACT_NONE || p.out32 || p.ln_x32 || (p.outT16 && p.out_lo_off && !p.outT_hi_only)) return false;
+  } else if (p.out_lo_off || !p.xs_pack) return false;
+  return ctx->use_xs && !p.a_lo_off && p.pool_w == 0 && p.K >= min_k && p.tile_hint == 0 && p.M >= min_m && (p.ln_x32 ? p.ln_ld == p.K : p.lda == p.K) && gemm_xs_supported(p.N, p.K) &&
          (p.act == ACT_NONE || p.act == ACT_GELU) && p.rope_cols == 0 && p.res_mod == 0 && !p.outT32 && (p.n_split >= p.N || (p.n_split & 31) == 0) &&
          !(p.out32 && p.out16) && (p.out32 || p.out16) && (!p.res || p.out32) && p.bias &&
          (!p.col_scale || (p.xs_scale_cols > 0 && p.xs_scale_cols <= 576 && (p.xs_scale_cols + 31) / 32 * 32 <= p.n_split));
@@ -136,10 +139,12 @@ static double gemm_algo_bytes(const GemmParams& p) {
   return b;
 }
 
+thread_local int tl_plan_group = GRP_NECK;
+
 int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p_in) {
   GemmParams p = p_in;
   if (ctx->precise) {            // split operands (activations: arena lo plane; weights: packed [hi | lo], or an arena buffer)
-    const int prec = (ctx->selective && p.prec != PREC_AUTO) ? p.prec : PREC_FULL;      // f16x3: every linear fully split
+    const int prec = !ctx->selective ? PREC_FULL : (p.prec != PREC_AUTO ? p.prec : ctx->plan_grp[tl_plan_group]);      // f16x3: every linear fully split
     if (prec == PREC_FULL) {
       if (!p.a_lo_off) p.a_lo_off = ctx->lo16;
       if (!p.w_lo_off) p.w_lo_off = ctx->lo16;
@@ -159,14 +164,15 @@ int run_gemm(sam2mi_ctx* ctx, hipStream_t s, const GemmParams& p_in) {
     return 0;
   }
   if (xs_eligible(ctx, p)) {
-    GemmXsParams x{p.A, p.lda, p.xs_pack, p.bias, p.col_scale, p.xs_scale_cols, p.act, p.M, p.N, p.n_split, p.out16, p.ld16, p.outT16, p.ldT16,
-                   p.out32, p.ld32, p.res, p.ldres, 0, p.ln_x32, p.ln_ld, p.ln_eps};
+    const bool ws = p.w_lo_off != 0;
+    GemmXsParams x{p.A, p.lda, ws ? p.xs_wpack : p.xs_pack, p.bias, p.col_scale, p.xs_scale_cols, p.act, p.M, p.N, p.n_split, p.out16, p.ld16, p.outT16, p.ldT16,
+                   p.out32, p.ld32, p.res, p.ldres, 0, p.ln_x32, p.ln_ld, p.ln_eps, ws ? 1 : 0, p.out_lo_off};
     hipEvent_t e0, e1;
     if (ctx->prof_on) prof_begin(ctx, ctx->prof_xs, s, e0, e1);
     CHK(gemm_xs_launch(x, p.K, s));
     if (ctx->prof_on) {
       char nm[96];
-      snprintf(nm, sizeof(nm), "gemm_xs_kernel<%d, %s, %s, 0>", p.K, p.act == ACT_GELU ? "true" : "false", p.out32 ? "true" : "false");
+      snprintf(nm, sizeof(nm), "gemm_xs_kernel<%d, %s, %s, 0%s>", p.K, p.act == ACT_GELU ? "true" : "false", p.out32 ? "true" : "false", ws ? ", true" : "");
       prof_end_named(ctx, ctx->prof_xs, nm, s, e0, e1, 2.0 * p.M * (double)p.N * p.K, gemm_algo_bytes(p));
     }
     return 0;
@@ -237,7 +243,7 @@ int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p) {
 
 GemmParams lin_params(const half_t* A, int lda, int M, const Lin16& L) {
   GemmParams p = gemm_params_zero();
-  p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.K; p.M = M; p.N = L.N; p.K = L.K; p.bias = L.b; p.n_split = L.N; p.xs_pack = L.xs_pack; p.ks_pack = L.ks_pack;
+  p.A = A; p.lda = lda; p.W = L.w; p.ldw = L.K; p.M = M; p.N = L.N; p.K = L.K; p.bias = L.b; p.n_split = L.N; p.xs_pack = L.xs_pack; p.xs_wpack = L.xs_wpack; p.ks_pack = L.ks_pack;
   p.w_lo_off = L.lo_off;
   return p;
 }
@@ -382,6 +388,72 @@ std::vector<float> sine_pe_nchw(int H, int W, int F) {
 
 extern "C" int sam2mi_abi_version(void) { return 2; }      // 2: sam2mi_config.precision
 
+// The selective-split plan of the f16s precision mode (tools/precision_shares.py and tools/precision_plan_video.py are the
+// CPU experiments behind it, tools/f16s_plan_sweep.sh the on-device one).  What carries the f16-mode error of the encoder is, in
+// this order: the rounding of WEIGHTS (coherent over all tokens: 4.6x the variance of all activation rounding together), of the
+// attention output that feeds the projection (near-uniform attention makes it coherent inside a window), of q / k; stages 1-2
+// and the attention linears of stage 3 matter, the MLP of stage 3 (2/3 of the encoder's FLOPs) and stage 4 hardly do.
+static bool f16s_plan_init(sam2mi_ctx* ctx) {
+  for (int st = 1; st <= 4; ++st)
+    for (int k = 0; k < 5; ++k) {
+      int v;
+      if (st == 4) v = PREC_F16;
+      else if (k == LIN_FC1 || k == LIN_FC2) v = PREC_F16;               // the MLPs (2/3 of the encoder's FLOPs) as in the f16 mode
+      else if (k == LIN_PROJ && st <= 2) v = PREC_FULL;                  // attention output of stages 1-2: x and W
+      else v = PREC_WSPLIT;                                              // QKV, stage-3 projection, transition shortcuts: W
+      ctx->plan[st][k] = v;
+    }
+  // outside the trunk: patch embedding + neck and the mask decoder on full splits (either in f16 alone breaks the 1e-3 bar: 1.3e-3 /
+  // 1.1e-3 max-abs on the 24-frame golden), memory attention and memory encoder in f16 (+5e-5 / +2e-5 of rel L2)
+  ctx->plan_grp[GRP_NECK] = ctx->plan_grp[GRP_DEC] = PREC_FULL;
+  ctx->plan_grp[GRP_MA] = ctx->plan_grp[GRP_MENC] = PREC_F16;
+  ctx->split_attn = true;
+  const char* e = getenv("SAM2MI_F16S_PLAN");
+  if (!e) return true;
+  std::string str(e);
+  size_t pos = 0;
+  while (pos < str.size()) {
+    size_t end = str.find(',', pos);
+    if (end == std::string::npos) end = str.size();
+    const std::string tok = str.substr(pos, end - pos);
+    pos = end + 1;
+    if (tok.empty()) continue;
+    const size_t eq = tok.find('=');
+    if (eq == std::string::npos) return false;
+    const std::string key = tok.substr(0, eq), val = tok.substr(eq + 1);
+    if (key == "attn") { ctx->split_attn = val != "0"; continue; }
+    const int v = val == "f16" ? PREC_F16 : val == "w" ? PREC_WSPLIT : val == "full" ? PREC_FULL : -1;
+    if (v < 0) return false;
+    if (key == "other") { for (int g = 0; g < 4; ++g) ctx->plan_grp[g] = v; continue; }
+    if (key == "neck") { ctx->plan_grp[GRP_NECK] = v; continue; }
+    if (key == "ma") { ctx->plan_grp[GRP_MA] = v; continue; }
+    if (key == "dec") { ctx->plan_grp[GRP_DEC] = v; continue; }
+    if (key == "menc") { ctx->plan_grp[GRP_MENC] = v; continue; }
+    const size_t dot = key.find('.');
+    if (dot == std::string::npos) return false;
+    const std::string sc = key.substr(0, dot), kd = key.substr(dot + 1);
+    int s0, s1;
+    if (sc == "s1") s0 = s1 = 1;
+    else if (sc == "s2") s0 = s1 = 2;
+    else if (sc == "s12") { s0 = 1; s1 = 2; }
+    else if (sc == "s3") s0 = s1 = 3;
+    else if (sc == "s4") s0 = s1 = 4;
+    else return false;
+    int k0, k1;
+    if (kd == "qkv") k0 = k1 = LIN_QKV;
+    else if (kd == "sc") k0 = k1 = LIN_SC;
+    else if (kd == "proj") k0 = k1 = LIN_PROJ;
+    else if (kd == "fc1") k0 = k1 = LIN_FC1;
+    else if (kd == "fc2") k0 = k1 = LIN_FC2;
+    else if (kd == "mlp") { k0 = LIN_FC1; k1 = LIN_FC2; }
+    else if (kd == "all") { k0 = 0; k1 = 4; }
+    else return false;
+    for (int st = s0; st <= s1; ++st)
+      for (int k = k0; k <= k1; ++k) ctx->plan[st][k] = v;
+  }
+  return true;
+}
+
 extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   if (!cfg || !out) return sam2mi_set_error(nullptr, "sam2mi_create", "null argument");
   int ndev = 0;
@@ -399,11 +471,16 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   }
   ctx->precise = ctx->cfg.precision != SAM2MI_PRECISION_F16;
   ctx->selective = ctx->cfg.precision == SAM2MI_PRECISION_F16S;
+  if (ctx->selective && !f16s_plan_init(ctx)) {
+    sam2mi_set_error(nullptr, "sam2mi_create", "SAM2MI_F16S_PLAN: expected <s1|s2|s12|s3|s4>.<qkv|sc|proj|fc1|fc2|mlp|all>=<f16|w|full>, <other|neck|ma|dec|menc>=<...>, attn=<0|1>");
+    delete ctx;
+    return 1;
+  }
   // the X-stationary / fused-MLP / accumulator-stationary kernels take plain f16 operands: the f16x3 mode runs every linear
   // on the split-operand instantiation of the tiled kernel (gemm2.hip)
-  ctx->use_fused_mlp = !ctx->precise && getenv("SAM2MI_NO_FUSED_MLP") == nullptr;
+  ctx->use_fused_mlp = (!ctx->precise || ctx->selective) && getenv("SAM2MI_NO_FUSED_MLP") == nullptr;      // f16s: where the plan has both MLP linears in f16
   ctx->use_xs = (!ctx->precise || ctx->selective) && getenv("SAM2MI_NO_XS") == nullptr;      // f16s: the linears planned as plain f16
-  ctx->use_rowln = !ctx->precise && getenv("SAM2MI_NO_ROWLN") == nullptr;
+  ctx->use_rowln = (!ctx->precise || (ctx->selective && ctx->plan_grp[GRP_MA] == PREC_F16)) && getenv("SAM2MI_NO_ROWLN") == nullptr;
   ctx->use_projln = !ctx->precise && getenv("SAM2MI_NO_PROJLN") == nullptr;
   // norm1 inside the operand load of the X-stationary QKV kernel: pays in stage 1 only (C = 144: the QKV launch goes 162 -> 200 us and the
   // 107-us LayerNorm launch disappears; same box, 8-frame pass 28.14 -> 27.89 ms with 144, 27.98 with 288, worse with 576)
@@ -575,6 +652,14 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
         L->xs_pack = (half_t*)dalloc(ctx, gemm_xs_pack_bytes(L->N, L->K));
         if (!L->xs_pack || gemm_xs_pack(L->w, L->N, L->K, L->K, L->xs_pack, nullptr) != hipSuccess) pk.ok = false;
       }
+      if (pk.ok && ctx->selective && b.qkv.w && b.qkv.lo_off && gemm_xs_supported(b.qkv.N, b.qkv.K) &&
+          ctx->plan[dim_out >= 1152 ? 4 : dim_out >= 576 ? 3 : dim_out >= 288 ? 2 : 1][LIN_QKV] == PREC_WSPLIT) {      // f16s: QKV on the weight-split X-stationary kernel
+        const size_t scratch_b = (size_t)2 * ((b.qkv.N + 31) / 32 * 32) * b.qkv.K * sizeof(half_t);
+        half_t* scratch = (half_t*)dalloc_raw(ctx, scratch_b);
+        b.qkv.xs_wpack = (half_t*)dalloc(ctx, gemm_xs_wsplit_pack_bytes(b.qkv.N, b.qkv.K));
+        if (!scratch || !b.qkv.xs_wpack || gemm_xs_wsplit_pack(b.qkv.w, b.qkv.w + b.qkv.lo_off, b.qkv.N, b.qkv.K, b.qkv.xs_wpack, scratch, nullptr) != hipSuccess) pk.ok = false;
+        if (scratch) { hipStreamSynchronize(nullptr); dfree(ctx, scratch); }
+      }
       // stages 1-2 only by default: at C = 576 a 32-row workgroup streams the whole 663-KB weight from L2 with 9 KB per wave in flight
       // and takes 89 us where GEMM + LayerNorm take 55 + 21 (C = 144: 184 vs 198 + 107 us, C = 288: 94 vs 106 + 41 us)
       static const int projln_max_c = getenv("SAM2MI_PROJLN_MAXC") ? atoi(getenv("SAM2MI_PROJLN_MAXC")) : 288;
@@ -626,7 +711,9 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
         if (!b.mlp_ln_pack || mlp_fused_pack(fc1_folded.w, b.fc2.w, b.dim_out, b.mlp_ln_pack, nullptr) != hipSuccess) pk.ok = false;
         b.fc1.b_ln = fc1_folded.b;
       }
-      if (pk.ok && !ctx->precise && mlp_fused_supported(b.dim_out)) {     // stages 1-2: weights also in the fused MLP kernel's piece order
+      const int pstage = dim_out >= 1152 ? 4 : dim_out >= 576 ? 3 : dim_out >= 288 ? 2 : 1;
+      const bool mlp_f16 = !ctx->precise || (ctx->selective && ctx->plan[pstage][LIN_FC1] == PREC_F16 && ctx->plan[pstage][LIN_FC2] == PREC_F16);
+      if (pk.ok && mlp_f16 && mlp_fused_supported(b.dim_out)) {     // stages 1-2: weights also in the fused MLP kernel's piece order
         b.mlp_pack = (half_t*)dalloc(ctx, mlp_fused_pack_bytes(b.dim_out));
         if (!b.mlp_pack || mlp_fused_pack(b.fc1.w, b.fc2.w, b.dim_out, b.mlp_pack, nullptr) != hipSuccess) pk.ok = false;
       }

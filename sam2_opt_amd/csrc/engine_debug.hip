@@ -64,6 +64,20 @@ extern "C" int sam2mi_debug_gemm(sam2mi_ctx* ctx, void* stream, const float* A, 
     CHK(hipStreamSynchronize(s));
     return 0;
   }
+  if (p.tile_hint == 32) {               // weight-split X-stationary kernel (f16s): A in f16, W as hi + lo; f16 hi + lo output folded back to f32
+    if (!gemm_xs_supported(N, K) || !split || (act & 0xFF) || residual) return sam2mi_set_error(ctx, __func__, "gemm_xs wsplit: split context, K in {144,288,576}, no activation / residual");
+    half_t* wp = t.get<half_t>(gemm_xs_wsplit_pack_bytes(N, K) / 2);
+    half_t* scratch = t.get<half_t>((size_t)2 * ((N + 31) / 32 * 32) * K);
+    half_t* o16 = t.get<half_t>((size_t)M * N * 2);
+    if (!wp || !scratch || !o16) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+    CHK(gemm_xs_wsplit_pack(w16, w16 + wlo, N, K, wp, scratch, s));
+    GemmXsParams x{a16, K, wp, bias, nullptr, 0, ACT_NONE, M, N, N, o16, N, nullptr, 0, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0.f, 1, (size_t)M * N};
+    CHK(gemm_xs_launch(x, K, s));
+    split_to_f32_kernel<<<dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s>>>(o16, (size_t)M * N, out, (size_t)M * N);
+    CHK(hipGetLastError());
+    CHK(hipStreamSynchronize(s));
+    return 0;
+  }
   if (p.tile_hint == 30) {               // X-stationary kernel (K = 144 / 288 / 576): pack W, then the production dispatch path
     if (!gemm_xs_supported(N, K)) return sam2mi_set_error(ctx, __func__, "gemm_xs needs K in {144,288,576}, N % 8 == 0");
     half_t* wp = t.get<half_t>(gemm_xs_pack_bytes(N, K) / 2);
@@ -86,6 +100,29 @@ extern "C" int sam2mi_debug_hiera_attention(sam2mi_ctx* ctx, void* stream, const
   hipStream_t s = (hipStream_t)stream;
   const int C = heads * 72, Mq = groups * GQ, Mk = groups * GK;
   Tmp t;
+  if (ctx->selective && ctx->split_attn && wq >= GQ && wk >= GK && GQ % 128 == 0 && (Mk & 7) == 0) {
+    // f16s context, the shapes of the shared-tile kernel: q / k as hi + lo planes, V^T in f16, output folded back from hi + lo
+    half_t* q16 = t.get<half_t>((size_t)Mq * C * 2);
+    half_t* k16 = t.get<half_t>((size_t)Mk * C * 2);
+    half_t* vT = t.get<half_t>((size_t)C * Mk);
+    half_t* o = t.get<half_t>((size_t)Mq * C * 2);
+    if (!q16 || !k16 || !vT || !o || Mq != Mk) return sam2mi_set_error(ctx, __func__, "hipMalloc failed (or GQ != GK)");
+    const size_t lo = (size_t)Mq * C;
+    CHK(cast_add_launch(q, C, q, C, 0, 1.4426950408889634f / sqrtf(72.f) - 1.f, Mq, C, q16, C, nullptr, 0, s, lo));   // pre-scaled q
+    CHK(cast_add_launch(k, C, nullptr, 0, 0, 0.f, Mk, C, k16, C, nullptr, 0, s, lo));
+    transpose_to_f16_kernel<<<dim3((unsigned)(((size_t)Mk * C + 255) / 256)), dim3(256), 0, s>>>(v, vT, Mk, C, Mk);
+    CHK(hipGetLastError());
+    HieraAttnParams a;
+    memset(&a, 0, sizeof(a));
+    a.q = q16; a.ldq = C; a.k = k16; a.ldk = C; a.vT = vT; a.ldvT = Mk; a.o = o; a.ldo = C; a.heads = heads;
+    a.GQ = GQ; a.GK = GK; a.wq = wq; a.wk = wk; a.num_groups = groups; a.scale_log2e = 1.4426950408889634f / sqrtf(72.f);
+    a.qk_lo_off = lo; a.o_lo_off = lo;
+    CHKI(run_hiera_attn(ctx, s, a));
+    split_to_f32_kernel<<<dim3((unsigned)(((size_t)Mq * C + 255) / 256)), dim3(256), 0, s>>>(o, lo, out, lo);
+    CHK(hipGetLastError());
+    CHK(hipStreamSynchronize(s));
+    return 0;
+  }
   if (ctx->precise) {                    // f16x3 context: the split-operand kernel on f32 inputs
     float* q32 = t.get<float>((size_t)Mq * C);
     float* vT32 = t.get<float>((size_t)C * Mk);

@@ -17,13 +17,10 @@ static const float LOG2E = 1.4426950408889634f;
 // order: the rounding of WEIGHTS (coherent over all tokens: 4.6x the variance of all activation rounding together), of the
 // attention output that feeds the projection (near-uniform attention makes it coherent inside a window), of q / k; stages 1-2
 // and the attention linears of stage 3 matter, the MLP of stage 3 (2/3 of the encoder's FLOPs) and stage 4 hardly do.
-enum { LIN_QKV, LIN_SC, LIN_PROJ, LIN_FC1, LIN_FC2 };
 static int plan_prec(const sam2mi_ctx* ctx, const HieraBlockW& b, int kind) {
   if (!ctx->selective) return PREC_AUTO;
-  if (b.dim_out >= 1152) return PREC_F16;                                        // stage 4
-  if (kind == LIN_PROJ || kind == LIN_SC) return PREC_FULL;                      // attention output / transition shortcut: x and W
-  if (b.dim_out >= 576) return kind == LIN_QKV ? PREC_WSPLIT : PREC_F16;         // stage 3: MLP as in the f16 mode
-  return PREC_WSPLIT;                                                            // stages 1-2: every weight
+  const int stage = b.dim_out >= 1152 ? 4 : b.dim_out >= 576 ? 3 : b.dim_out >= 288 ? 2 : 1;
+  return ctx->plan[stage][kind];
 }
 
 int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, int B, int& H, int& W, int& wcur) {
@@ -31,7 +28,7 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   const int C = b.dim, Co = b.dim_out;
   float* x = ctx->ws_x;
   // lo planes of the two LayerNorm outputs: only where a consumer splits its activation operand
-  const size_t ln1_lo = (ctx->selective && !(b.q_pool && plan_prec(ctx, b, LIN_SC) == PREC_FULL)) ? 0 : ctx->lo16;
+  const size_t ln1_lo = (ctx->selective && plan_prec(ctx, b, LIN_QKV) != PREC_FULL && !(b.q_pool && plan_prec(ctx, b, LIN_SC) == PREC_FULL)) ? 0 : ctx->lo16;
   const size_t ln2_lo = (ctx->selective && plan_prec(ctx, b, LIN_FC1) != PREC_FULL) ? 0 : ctx->lo16;
   // 1. LN1 - as a kernel of its own only when the QKV projection cannot normalise its operand rows itself
   GemmParams qkv_p = lin_params(ctx->ws_a16, C, M, b.qkv);
@@ -59,6 +56,10 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
       CHK(pool_tokens_f32_launch(ctx->ws_x2, Co, x, Co, M / (wcur * wcur), wcur, Co, s));
     }
   }
+  // f16s: the shapes of the shared-tile attention kernel (stage-3 windows, global blocks) take q / k as f16 hi + lo planes and
+  // V^T as plain f16 (attn_hiera.hip, SPLIT); the others (pooled queries, packed small windows) stay on attn_precise.hip
+  const int win_n = b.window > 0 ? wcur * wcur : H * W;
+  const bool split_attn = ctx->selective && ctx->split_attn && !b.q_pool && (win_n % 128) == 0 && (M & 7) == 0;
   // 2. QKV projection: q|k row-major, v transposed (attention consumes V^T tiles)
   {
     GemmParams p = qkv_p;
@@ -67,7 +68,8 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
     p.col_scale = b.qscale;                 // q pre-scaled (f32, before the f16 rounding) for the exp2-domain softmax
     p.xs_scale_cols = Co;                   // k / v columns have scale 1
     p.prec = plan_prec(ctx, b, LIN_QKV);
-    if (ctx->precise) {                     // f16x3 mode: the attention kernel takes f32 q / k / V^T and splits them itself
+    p.outT_hi_only = split_attn;
+    if (ctx->precise && !split_attn) {      // f16x3 mode: the attention kernel takes f32 q / k / V^T and splits them itself
       p.out32 = ctx->ws_qk32; p.ld32 = 2 * Co;
       p.outT32 = ctx->ws_vT32; p.ldT32 = M;
     } else {
@@ -77,7 +79,7 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
     CHKI(run_gemm(ctx, s, p));
   }
   // 3. attention
-  if (ctx->precise) {
+  if (ctx->precise && !split_attn) {
     PreciseAttnParams a;
     memset(&a, 0, sizeof(a));
     a.k = ctx->ws_qk32 + Co; a.ldk = 2 * Co;
@@ -109,6 +111,7 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   a.o = ctx->ws_att16; a.ldo = Co;
   a.heads = b.heads;
   a.scale_log2e = LOG2E / sqrtf(72.f);
+  if (split_attn) a.qk_lo_off = a.o_lo_off = ctx->lo16;
   const int win = (b.window > 0) ? wcur : 0;
   if (!b.q_pool) {
     a.q = ctx->ws_qk16; a.ldq = 2 * Co;
@@ -306,6 +309,7 @@ static int trunk_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, const
 }
 
 int encoder_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, int B, const EncOut* outs, const uint8_t* img_u8) {
+  PlanGroup plan_group(GRP_NECK);
   const sam2mi_config& c = ctx->cfg;
   if (!ctx->finalized) return sam2mi_set_error(ctx, "encoder_forward", "weights not finalized");
   if (B <= 0 || B > c.max_batch) return sam2mi_set_error(ctx, "encoder_forward", "batch exceeds cfg.max_batch");

@@ -46,6 +46,7 @@ static int attn_tail(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& f, co
 int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const float* curr_pos, int N, const int* Nk, const int* n_rope,
                     float* out32) {
   const int S = 4096, C = 256;
+  PlanGroup plan_group(GRP_MA);
   if (N < 1 || N > TRACK_MAX_N) return sam2mi_set_error(ctx, "memattn_forward", "object batch out of range (1..TRACK_MAX_N)");
   const int M = N * S;
   const size_t cap = (size_t)ctx->t_nk_cap;
@@ -195,6 +196,7 @@ static int refresh_key_operands(sam2mi_ctx* ctx, hipStream_t s, const float* pos
 // null: none), in.pos_tok [4096,256] shared or [N,4096,256], in.tokens [N,T,256], hr0 [65536,32] / hr1 [16384,64] per prompt or shared.
 // Results land in ctx->d_masks [N,4,65536], d_iou [N,4], d_mtok [N,4,256], d_obj [N].
 int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, int T) {
+  PlanGroup plan_group(GRP_DEC);
   if (T < 6 || T > 64) return sam2mi_set_error(ctx, "decoder_forward", "token count out of range (6..64)");
   if (N < 1 || N > DEC_MAX_N) return sam2mi_set_error(ctx, "decoder_forward", "prompt batch out of range (1..DEC_MAX_N)");
   const int R = N * T, M = N * 4096;
@@ -294,6 +296,7 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
 // MemoryEncoder.inference_memory_torch (modeling/memory_encoder.py:233-241): feat2_tok [4096,256] raw
 // vision features, mask1024 [1024*1024] already sigmoid-scaled -> out_tok64 [4096,64] f32.
 int memenc_forward(sam2mi_ctx* ctx, hipStream_t s, const float* feat2_tok, const float* mask1024, float* out_tok64, const float* low256, int binarize) {
+  PlanGroup plan_group(GRP_MENC);
   // MaskDownSampler: 4 x (conv3x3 s2 + LN2d + GELU), then 1x1
   if (mask1024) CHK(conv3x3s2_ln_gelu_launch(mask1024, 1024, 1, 4, ctx->md_w[0], ctx->md_b[0], ctx->md_ln[0].w, ctx->md_ln[0].b, ctx->m_c1, nullptr, s, ctx->lo16));
   else          // fused video path: bilinear x4 + sigmoid / binarise + scale folded into the first conv

@@ -41,6 +41,8 @@ struct GemmParams {
   // PREC_AUTO = the context's default (f16 / full split), PREC_F16 / PREC_WSPLIT / PREC_FULL = this linear's entry in the
   // selective plan; no_out_lo: the f16 output feeds a consumer that reads the hi plane only - skip the lo plane
   int prec, no_out_lo;
+  const half_t* xs_wpack;        // weight-split image of the X-stationary kernel (gemm_xs_wsplit_pack), or null
+  int outT_hi_only;              // the consumer of outT16 reads its hi plane only (lets the weight-split X-stationary kernel take the launch)
   // LayerNorm fused into the operand load of the X-stationary kernel (gemm_xs.h): A is ignored, the operand is the normalised
   // row of ln_x32 [M, K] (ln_ld floats per row); xs_pack / bias must be the LN-folded ones.  X-stationary shapes only.
   const float* ln_x32; int ln_ld; float ln_eps;

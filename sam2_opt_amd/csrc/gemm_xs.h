@@ -24,9 +24,15 @@ struct GemmXsParams {
   // LayerNorm fused into the operand load (x16 ignored): X = (x32 - mean) * rstd per row, statistics over all K channels of
   // the row; the weight / bias must carry the affine part (Lin16::xs_ln_pack).  ldx32 % 4 == 0.
   const float* ln_x32; int ldx32; float ln_eps;
+  // weight split (f16s precision mode): wpack is the image of gemm_xs_wsplit_pack ([W_hi | W_lo] chunk pairs), two MFMA chains per
+  // output tile; f16 outputs without activation only.  out_lo_off != 0: out16 is written as hi + lo planes (outT16: hi only)
+  int wsplit; size_t out_lo_off;
 };
 bool gemm_xs_supported(int N, int K);
 size_t gemm_xs_pack_bytes(int N, int K);
 hipError_t gemm_xs_pack(const half_t* w, int N, int K, int ldw, half_t* wpack, hipStream_t s);
+size_t gemm_xs_wsplit_pack_bytes(int N, int K);
+// scratch: 2 * ceil32(N) * K halfs (the interleaved [hi | lo] matrix; may be released after the stream has run)
+hipError_t gemm_xs_wsplit_pack(const half_t* w_hi, const half_t* w_lo, int N, int K, half_t* wpack, half_t* scratch, hipStream_t s);
 hipError_t gemm_xs_launch(const GemmXsParams& p, int K, hipStream_t s);
 hipError_t gemm_xs_init();

@@ -45,11 +45,18 @@ template <int K> constexpr int frag_batch() { return K == 144 ? 5 : 6; }   // fr
 
 // GELU: erf-GELU on the row-major columns; F32: f32 output (+ residual) instead of f16 for the row-major columns
 // ABL != 0: timing ablations (wrong results; tuning aid): 1 no LDS-DMA in the loop, 2 no MFMA, 3 no output stores
-template <int K, bool GELU, bool F32, int ABL = 0>
+// WS (weight split, the f16s precision mode): the packed image holds W as a 2-term f16 split, chunk 2j = rows of W_hi, chunk 2j+1 =
+// the same rows of W_lo (lo = f16((w - hi) * 2^11), common.h); a logical chunk takes both chains - X W_hi^T into the main
+// accumulator, X W_lo^T into a second one that is folded in x 2^-11 - so the rounding of the weights (the coherent part of the
+// f16-mode error) is gone at 2x the MFMA work and 2x the weight stream, X still read once.  K = 576 (one chunk per stage): the
+// two halves of a logical chunk sit in consecutive ring stages and the stage loop advances by two.
+template <int K, bool GELU, bool F32, int ABL = 0, bool WS = false>
 __global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams p) {
   constexpr int KS = K / 16;             // k-steps = pieces per chunk
   constexpr int CPS = STAGE_PIECES / KS; // chunks (of 32 output columns) per stage
   constexpr int FB = frag_batch<K>();
+  constexpr int LS = (WS && CPS == 1) ? 2 : 1;      // ring stages per loop iteration
+  constexpr int LCS = WS ? 1 : 0;                   // log2(physical chunks per logical chunk)
   static_assert(KS * CPS == STAGE_PIECES, "K must divide 576");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -57,8 +64,9 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams 
   const int fr = lane & 31, fh = lane >> 5;
   const int tok0 = (blockIdx.x * NW + wave) * 32;
   // this workgroup's stage range (column split)
-  const int nstages = (p.N + 32 * CPS - 1) / (32 * CPS);
-  const int per = (nstages + gridDim.y - 1) / gridDim.y;
+  const int nchunks = ((p.N + 31) / 32) << LCS;             // physical chunks
+  const int nstages = ((nchunks + CPS - 1) / CPS + LS - 1) / LS * LS;
+  const int per = ((nstages / LS + gridDim.y - 1) / gridDim.y) * LS;
   const int st_lo = blockIdx.y * per, st_hi = min(nstages, st_lo + per);
   if (st_lo >= st_hi) return;
 
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams 
   // at the top of every chunk sits in front of the MFMA chain it initialises (measured: ~1 us per chunk under load)
   float* bias_lds = reinterpret_cast<float*>(smem + NST * STAGE_B);
   float* scale_lds = bias_lds + MAX_COLS;
-  const int col_lo = st_lo * CPS * 32, col_hi = min(p.N, st_hi * CPS * 32);
+  const int col_lo = (st_lo * CPS * 32) >> LCS, col_hi = min(p.N, (st_hi * CPS * 32) >> LCS);
   for (int i = tid; i < MAX_COLS; i += 64 * NW) bias_lds[i] = (col_lo + i < col_hi) ? p.bias[col_lo + i] : 0.f;
   for (int i = tid; i < MAX_SCALE; i += 64 * NW) scale_lds[i] = (p.col_scale && col_lo + i < p.scale_cols) ? p.col_scale[col_lo + i] : 1.f;
   __syncthreads();
@@ -125,16 +133,16 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams 
     }
   };
   // row-major columns: S^T = W_chunk X^T; register 8 ks + e <-> column n0 + 16 ks + 8 fh + e of token fr
-  auto chunk_row = [&](const char* sW, int n0) {
+  auto row_init = [&](int n0) {
     f32x16 sa;
-    {
-      const float* bp = bias_lds + (n0 - col_lo) + 8 * fh;       // the bias is the initial accumulator (zero past N)
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
-      const f32x4 b2 = *reinterpret_cast<const f32x4*>(bp + 16), b3 = *reinterpret_cast<const f32x4*>(bp + 20);
+    const float* bp = bias_lds + (n0 - col_lo) + 8 * fh;       // the bias is the initial accumulator (zero past N)
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+    const f32x4 b2 = *reinterpret_cast<const f32x4*>(bp + 16), b3 = *reinterpret_cast<const f32x4*>(bp + 20);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { sa[e] = b0[e]; sa[4 + e] = b1[e]; sa[8 + e] = b2[e]; sa[12 + e] = b3[e]; }
-    }
-    chain(sW, sa, std::false_type{});
+    for (int e = 0; e < 4; ++e) { sa[e] = b0[e]; sa[4 + e] = b1[e]; sa[8 + e] = b2[e]; sa[12 + e] = b3[e]; }
+    return sa;
+  };
+  auto row_fin = [&](const f32x16& sa, int n0) {
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = GELU ? gelu_erf_fast(sa[r]) : sa[r];
@@ -165,21 +173,27 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams 
           *reinterpret_cast<f32x4*>(op) = a;
           *reinterpret_cast<f32x4*>(op + 4) = b;
         } else {
-          half8 h;
+          half8 h, l;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) h[e] = (half_t)v[8 * ks + e];
+          for (int e = 0; e < 8; ++e) {
+            h[e] = (half_t)v[8 * ks + e];
+            if (WS) l[e] = split_lo(v[8 * ks + e], h[e]);
+          }
           *reinterpret_cast<half8*>(p.out16 + (size_t)tok * p.ld16 + n) = h;
+          if (WS && p.out_lo_off) *reinterpret_cast<half8*>(p.out16 + p.out_lo_off + (size_t)tok * p.ld16 + n) = l;
         }
       }
     }
   };
   // transposed columns (V^T): S = X W_chunk^T; register r <-> token tok0 + (r & 3) + 8 (r >> 2) + 4 fh of column n0 + fr
-  auto chunk_trans = [&](const char* sW, int n0) {
+  auto trans_init = [&](int n0) {
     f32x16 sa;
     const float bt = bias_lds[n0 - col_lo + fr];
 #pragma unroll
     for (int r = 0; r < 16; ++r) sa[r] = bt;
-    chain(sW, sa, std::true_type{});
+    return sa;
+  };
+  auto trans_fin = [&](const f32x16& sa, int n0) {
     if (n0 + fr < p.N) {
       half_t* op = p.outT16 + (size_t)(n0 - p.n_split + fr) * p.ldT16 + tok0 + 4 * fh;
 #pragma unroll
@@ -197,28 +211,73 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams 
     }
   };
 
+  auto zero16 = [] {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+  };
+  auto fold = [](f32x16& sa, const f32x16& sc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sa[r] = fmaf(sc[r], SPLIT_INV, sa[r]);
+  };
   issue(st_lo);
   issue(st_lo + 1);
+  if constexpr (WS && CPS == 1) {
+    // K = 576, weight split: stage st = W_hi rows of logical chunk st / 2, stage st + 1 = their W_lo.  Vector-memory order of a
+    // wave at the first wait (old -> young): pieces(st) | pieces(st+1) | stores(st-2, st-1: >= 2), at the second one
+    // pieces(st+1) | stores | pieces(st+2): both may leave PPW + 2 operations outstanding (PPW where a wave may have stored nothing)
+#pragma nounroll
+    for (int st = st_lo; st < st_hi; st += 2) {
+      const int n0 = (st >> 1) * 32;
+      const bool row = n0 < p.n_split;
+      const bool counted = st != st_lo && !(p.M & (32 * NW - 1));
+      if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(st + 2);
+      f32x16 sa, sc = zero16();
+      if (row) { sa = row_init(n0); chain(smem + ((st - st_lo) % NST) * STAGE_B + rd_perm, sa, std::false_type{}); }
+      else { sa = trans_init(n0); chain(smem + ((st - st_lo) % NST) * STAGE_B + rd_nat, sa, std::true_type{}); }
+      if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(st + 3);
+      if (row) { chain(smem + ((st + 1 - st_lo) % NST) * STAGE_B + rd_perm, sc, std::false_type{}); fold(sa, sc); row_fin(sa, n0); }
+      else { chain(smem + ((st + 1 - st_lo) % NST) * STAGE_B + rd_nat, sc, std::true_type{}); fold(sa, sc); trans_fin(sa, n0); }
+    }
+  } else {
+  constexpr int SPS = WS ? CPS : 2 * CPS;                 // stores per stage a wave issues at least (2 per logical chunk)
 #pragma nounroll
   for (int st = st_lo; st < st_hi; ++st) {
     // Stage st landed; stage st+1 stays in flight.  Vector-memory order of a wave (old -> young):
-    //   pieces(st) | stores(st-2) | pieces(st+1) | stores(st-1)          (5 pieces per stage; >= 2 stores per chunk)
+    //   pieces(st) | stores(st-2) | pieces(st+1) | stores(st-1)          (5 pieces per stage; >= 2 stores per logical chunk)
     // vmcnt retires in order, so with N outstanding allowed, N <= (operations younger than pieces(st)) keeps every piece of
-    // stage st complete: 5 in the first iteration, 5 + 2 CPS in the second, 5 + 4 CPS afterwards - without waiting for the
+    // stage st complete: 5 in the first iteration, 5 + SPS in the second, 5 + 2 SPS afterwards - without waiting for the
     // store acknowledgements.  M % 256 != 0: some waves store nothing -> 5.
     if (st == st_lo || (p.M & (32 * NW - 1))) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-    else if (st == st_lo + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2 * CPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 4 * CPS) : "memory");
+    else if (st == st_lo + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + SPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2 * SPS) : "memory");
     __builtin_amdgcn_s_barrier();                         // ... for every wave; everyone is past stage st-1 -> its slot is free
     if (ABL != 1) issue(st + 2);
     const char* sb = smem + ((st - st_lo) % NST) * STAGE_B;
 #pragma unroll
-    for (int c = 0; c < CPS; ++c) {
-      const int n0 = (st * CPS + c) * 32;
+    for (int c = 0; c < CPS; c += 1 << LCS) {
+      const int n0 = ((st * CPS + c) >> LCS) * 32;
       if (n0 >= p.N) break;                               // wave-uniform (zero-padded tail of the packed image)
-      if (n0 < p.n_split) chunk_row(sb + c * KS * 1024 + rd_perm, n0);
-      else chunk_trans(sb + c * KS * 1024 + rd_nat, n0);
+      if (n0 < p.n_split) {
+        f32x16 sa = row_init(n0);
+        chain(sb + c * KS * 1024 + rd_perm, sa, std::false_type{});
+        if (WS) { f32x16 sc = zero16(); chain(sb + (c + 1) * KS * 1024 + rd_perm, sc, std::false_type{}); fold(sa, sc); }
+        row_fin(sa, n0);
+      } else {
+        f32x16 sa = trans_init(n0);
+        chain(sb + c * KS * 1024 + rd_nat, sa, std::true_type{});
+        if (WS) { f32x16 sc = zero16(); chain(sb + (c + 1) * KS * 1024 + rd_nat, sc, std::true_type{}); fold(sa, sc); }
+        trans_fin(sa, n0);
+      }
     }
+  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // trailing duplicate pieces land before the LDS is released
 }
@@ -244,9 +303,35 @@ __global__ void gemm_xs_pack_kernel(const half_t* __restrict__ w, int N, int ldw
   *reinterpret_cast<half8*>(out + u * 8) = v;
 }
 
+// the virtual weight matrix of the weight-split image: row 64 j + r = W_hi row 32 j + r, row 64 j + 32 + r = W_lo row 32 j + r (zero past N)
+__global__ void gemm_xs_interleave_kernel(const half_t* __restrict__ hi, const half_t* __restrict__ lo, int N, int K, half_t* __restrict__ out, long total) {
+  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= total) return;
+  const long row = u / K;
+  const int k = (int)(u - row * K);
+  const long n = (row >> 6) * 32 + (row & 31);
+  out[u] = n < N ? (((row >> 5) & 1) ? lo : hi)[n * K + k] : (half_t)0.f;
+}
+
 template <int K>
 hipError_t launch_k(const GemmXsParams& p, hipStream_t s) {
   constexpr int CPS = STAGE_PIECES / (K / 16);
+  if (p.wsplit) {
+    constexpr int LS = CPS == 1 ? 2 : 1;
+    const int nchunks = 2 * ((p.N + 31) / 32);
+    const int nstages = ((nchunks + CPS - 1) / CPS + LS - 1) / LS * LS;
+    const int tb = (p.M + 32 * NW - 1) / (32 * NW);
+    const int groups = nstages / LS;
+    const int max_groups = 2 * MAX_COLS / (32 * CPS) / LS;              // bias table: at most MAX_COLS logical columns per workgroup
+    int splits = p.splits > 0 ? p.splits : (256 + tb - 1) / tb;
+    splits = std::max(splits, (groups + max_groups - 1) / max_groups);
+    splits = std::max(1, std::min(splits, groups));
+    if ((groups + splits - 1) / splits > max_groups) return hipErrorInvalidValue;
+    const dim3 grid(tb, splits), block(64 * NW);
+    if (p.out32 || p.act != ACT_NONE) return hipErrorInvalidValue;      // f16 outputs, no activation: the QKV projections
+    gemm_xs_kernel<K, false, false, 0, true><<<grid, block, LDS_B, s>>>(p);
+    return hipGetLastError();
+  }
   const int nstages = (p.N + 32 * CPS - 1) / (32 * CPS);
   const int tb = (p.M + 32 * NW - 1) / (32 * NW);
   // column splits: fill the chip with two workgroups per CU (512 slots) at least once, never more splits than stages
@@ -278,6 +363,7 @@ hipError_t attr_k() {
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, false, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, false, false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
   return e;
 }
 }  // namespace
@@ -306,6 +392,16 @@ hipError_t gemm_xs_pack(const half_t* w, int N, int K, int ldw, half_t* wpack, h
   else if (K == 288) gemm_xs_pack_kernel<288><<<grid, block, 0, s>>>(w, N, ldw, wpack, units);
   else gemm_xs_pack_kernel<576><<<grid, block, 0, s>>>(w, N, ldw, wpack, units);
   return hipGetLastError();
+}
+
+size_t gemm_xs_wsplit_pack_bytes(int N, int K) { return gemm_xs_pack_bytes(2 * ((N + 31) / 32) * 32, K); }
+
+hipError_t gemm_xs_wsplit_pack(const half_t* w_hi, const half_t* w_lo, int N, int K, half_t* wpack, half_t* scratch, hipStream_t s) {
+  const int rows = 2 * ((N + 31) / 32) * 32;
+  const long total = (long)rows * K;
+  gemm_xs_interleave_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(w_hi, w_lo, N, K, scratch, total);
+  hipError_t e = hipGetLastError();
+  return e != hipSuccess ? e : gemm_xs_pack(scratch, rows, K, K, wpack, s);
 }
 
 hipError_t gemm_xs_launch(const GemmXsParams& p, int K, hipStream_t s) {

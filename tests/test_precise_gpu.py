@@ -84,6 +84,47 @@ def test_precise_attention(eng3, groups, heads, GQ, GK, wq, wk):
     check(f"precise_attn g{groups} h{heads} {GQ}/{GK} w{wq}/{wk}", out, ref, 2e-5, 1e-5)
 
 
+# ----------------------------------------------------------------------------- kernels of the selective mode (f16s)
+@pytest.fixture(scope="module")
+def engs(sd_large):
+    from sam2_opt_amd.native import Engine
+    e = Engine("large", state_dict=sd_large, max_batch=2, precision="f16s")
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1728, 576), (32768, 1728, 576), (1000, 576, 576), (2048, 432, 144), (3000, 864, 288),
+                                   (512, 1152, 288), (130, 144, 144), (256, 40, 576), (256, 3456, 576)])
+def test_gemm_xs_weight_split(engs, M, N, K):
+    """Weight-split X-stationary GEMM (gemm_xs_kernel<..., WS>: QKV of the f16s mode): activations rounded to f16 (that operand is
+    not split), weights NOT representable in f16; the f16 hi + lo output planes folded back to f32.  Against fp64: what is left
+    is the dropped lo rounding (2^-22) and the f32 accumulation - the f16 rounding of W alone would leave 3e-4."""
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K + 2)
+    A = torch.randn(M, K, generator=g).half().float()
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    W[: N // 4] *= 1e-3                                  # small weights: lo ~ 1e-8 before scaling
+    b = torch.randn(N, generator=g)
+    out = engs.debug_gemm(A.cuda(), W.cuda(), b.cuda(), 0, None, tile_hint=32)
+    ref = A.double() @ W.double().t() + b.double()
+    check(f"gemm_xs wsplit {M}x{N}x{K}", out, ref.float(), 1e-5, 3e-6)
+
+
+@pytest.mark.parametrize("groups,heads,GQ,GK", [(2, 8, 256, 256), (9, 8, 256, 256), (1, 8, 1024, 1024), (2, 8, 4096, 4096), (3, 2, 128, 128)])
+def test_split_qk_attention(engs, groups, heads, GQ, GK):
+    """hiera_attn_v2_kernel<SPLIT> (stage-3 windows and global blocks of the f16s mode): q / k as 2-term f16 splits (three products
+    for the scores), p and v in f16.  Unrounded q / k, f16-rounded v; a spiked key makes the running maximum jump late in the sweep.
+    With f16 q / k the same inputs give 3e-4 (test_hiera_attention's tolerance is 4e-3); here the f16 probabilities are what is left."""
+    g = torch.Generator(device="cpu").manual_seed(groups * 100 + GQ + GK + 1)
+    C = heads * 72
+    q = (torch.randn(groups * GQ, C, generator=g) * 1.5)
+    k = (torch.randn(groups * GK, C, generator=g) * 1.5)
+    k[GK - 3, :72] = q[5, :72] * 1.5
+    v = torch.randn(groups * GK, C, generator=g).half().float()
+    out = engs.debug_hiera_attention(q.cuda(), k.cuda(), v.cuda(), groups, heads, GQ, GK, GQ, GK)
+    ref = _ref_attn(q.cuda(), k.cuda(), v.cuda(), groups, heads, GQ, GK, GQ, GK)
+    check(f"split_qk_attn g{groups} h{heads} {GQ}/{GK}", out, ref, 1e-3, 3e-4)
+
+
 # ----------------------------------------------------------------------------- plugs vs the oracle
 @pytest.fixture(scope="module")
 def oracle_enc(sd_large, cfg_large):
