@@ -20,9 +20,12 @@ constexpr int K_TILE = 32 * KROW;     // halfs
 constexpr int V_TILE = 96 * VROW;     // halfs (rows 72..95 are never written; their products are discarded)
 constexpr int REGION = K_TILE + V_TILE;
 
-template <bool SHARE, bool MASK>
+// SPLIT (f16s precision mode): q / k as 2-term f16 splits (lo plane qk_lo_off elements behind the hi plane), three products for
+// the scores, output as hi + lo - see hiera_attn_v2_kernel<SPLIT> below; the K_lo tile sits behind the V^T tile of a region.
+template <bool SHARE, bool MASK, bool SPLIT = false>
 __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p) {
-  __shared__ __attribute__((aligned(16))) half_t smem[(SHARE ? 1 : 4) * REGION];
+  constexpr int REG = REGION + (SPLIT ? K_TILE : 0);
+  __shared__ __attribute__((aligned(16))) half_t smem[(SHARE ? 1 : 4) * REG];
   constexpr int NTHR = SHARE ? 256 : 64;
   constexpr int K_IT = (32 * 9 + NTHR - 1) / NTHR;      // 16-B chunks of the K tile per thread
   constexpr int V_IT = (HD * 8 + NTHR - 1) / NTHR;      // 8-B chunks of the V^T tile per thread
@@ -38,21 +41,28 @@ __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p
   const int gh = task / qtiles;
   const int head = gh % p.heads, grp = gh / p.heads;
 
-  half_t* sK = smem + (SHARE ? 0 : wave * REGION);
+  half_t* sK = smem + (SHARE ? 0 : wave * REG);
   half_t* sV = sK + K_TILE;
+  half_t* sKl = sK + REGION;            // SPLIT only
   // zero the head-dim pad (cols 72..87) of the K tile once; staging never touches it
-  for (int i = st; i < 32 * 16; i += NTHR) sK[(i >> 4) * KROW + HD + (i & 15)] = (half_t)0.f;
+  for (int i = st; i < 32 * 16; i += NTHR) {
+    sK[(i >> 4) * KROW + HD + (i & 15)] = (half_t)0.f;
+    if (SPLIT) sKl[(i >> 4) * KROW + HD + (i & 15)] = (half_t)0.f;
+  }
 
   // ---- Q fragments (B operand): lane holds Q[q = fr][d = 16 s + 8 fh + j]; Q is pre-scaled by 72^-0.5 * log2(e)
   const size_t qrow = (size_t)grp * p.GQ + qt * 32 + fr;
-  half8 qf[5];
+  half8 qf[5], ql[SPLIT ? 5 : 1];
 #pragma unroll
   for (int s = 0; s < 5; ++s) {
     if (s == 4 && fh == 1) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) qf[s][j] = (half_t)0.f;
+      if (SPLIT) ql[SPLIT ? s : 0] = qf[s];
     } else {
-      qf[s] = *reinterpret_cast<const half8*>(p.q + qrow * p.ldq + head * HD + s * 16 + fh * 8);
+      const half_t* qp = p.q + qrow * p.ldq + head * HD + s * 16 + fh * 8;
+      qf[s] = *reinterpret_cast<const half8*>(qp);
+      if (SPLIT) ql[SPLIT ? s : 0] = *reinterpret_cast<const half8*>(qp + p.qk_lo_off);
     }
   }
 
@@ -73,13 +83,17 @@ __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p
   const half_t* vbase = p.vT + (size_t)head * HD * p.ldvT + (size_t)grp * p.GK;
 
   // register-staged tiles: the loads of tile t+1 are issued before the MFMAs of tile t
-  half8 rk[K_IT];
+  half8 rk[K_IT], rkl[SPLIT ? K_IT : 1];
   half4 rv[V_IT];
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < K_IT; ++i) {
       const int c = st + i * NTHR;
-      if (c < 32 * 9) rk[i] = *reinterpret_cast<const half8*>(kbase + (size_t)(k0 + c / 9) * p.ldk + (c % 9) * 8);
+      if (c < 32 * 9) {
+        const half_t* kp = kbase + (size_t)(k0 + c / 9) * p.ldk + (c % 9) * 8;
+        rk[i] = *reinterpret_cast<const half8*>(kp);
+        if (SPLIT) rkl[SPLIT ? i : 0] = *reinterpret_cast<const half8*>(kp + p.qk_lo_off);
+      }
     }
 #pragma unroll
     for (int i = 0; i < V_IT; ++i) {
@@ -91,7 +105,10 @@ __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p
 #pragma unroll
     for (int i = 0; i < K_IT; ++i) {
       const int c = st + i * NTHR;
-      if (c < 32 * 9) *reinterpret_cast<half8*>(sK + (c / 9) * KROW + (c % 9) * 8) = rk[i];
+      if (c < 32 * 9) {
+        *reinterpret_cast<half8*>(sK + (c / 9) * KROW + (c % 9) * 8) = rk[i];
+        if (SPLIT) *reinterpret_cast<half8*>(sKl + (c / 9) * KROW + (c % 9) * 8) = rkl[SPLIT ? i : 0];
+      }
     }
 #pragma unroll
     for (int i = 0; i < V_IT; ++i) {
@@ -115,6 +132,20 @@ __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p
     for (int ks = 0; ks < 5; ++ks) {
       const half8 kf = *reinterpret_cast<const half8*>(sK + fr * KROW + ks * 16 + fh * 8);
       s = mfma32(kf, qf[ks], s);
+    }
+    if (SPLIT) {                    // cross terms in their own chain, folded in x 2^-11
+      f32x16 sc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 5; ++ks) {
+        const half8 kf = *reinterpret_cast<const half8*>(sK + fr * KROW + ks * 16 + fh * 8);
+        const half8 kl = *reinterpret_cast<const half8*>(sKl + fr * KROW + ks * 16 + fh * 8);
+        sc = mfma32(kl, qf[ks], sc);
+        sc = mfma32(kf, ql[SPLIT ? ks : 0], sc);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = fmaf(sc[r], SPLIT_INV, s[r]);
     }
     float tmax = -1e30f;
 #pragma unroll
@@ -170,9 +201,15 @@ __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p
       for (int g = 0; g < 4; ++g) {
         const int d = t * 32 + 8 * g + 4 * fh;
         if (d < HD) {
-          const half4 h = {(half_t)(o[t][4 * g] * inv), (half_t)(o[t][4 * g + 1] * inv),
-                           (half_t)(o[t][4 * g + 2] * inv), (half_t)(o[t][4 * g + 3] * inv)};
+          half4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = o[t][4 * g + e] * inv;
+            h[e] = (half_t)v;
+            if (SPLIT) l[e] = split_lo(v, h[e]);
+          }
           *reinterpret_cast<half4*>(orow + d) = h;
+          if (SPLIT && p.o_lo_off) *reinterpret_cast<half4*>(orow + p.o_lo_off + d) = l;
         }
       }
     }
@@ -434,9 +471,16 @@ hipError_t hiera_attn_launch(const HieraAttnParams& p, hipStream_t stream) {
   const int blocks = (total + 3) / 4;
   const bool mask = !(p.wq >= p.GQ && p.wk >= p.GK);
   static const bool use_v1 = getenv("SAM2MI_HATTN_V1") != nullptr;     // A/B switch: the register-staged kernel
-  if (p.qk_lo_off) {                // split q / k: only the shapes the shared-tile kernel takes (the caller routes the others elsewhere)
-    if (qtiles % 4 || mask || (p.ldvT & 7) || (p.qk_lo_off & 7) || (p.o_lo_off & 3)) return hipErrorInvalidValue;
-    hiera_attn_v2_kernel<true><<<dim3(total / 4), dim3(256), 0, stream>>>(p);
+  if (p.qk_lo_off) {                // split q / k (f16s precision mode)
+    if ((p.qk_lo_off & 7) || (p.o_lo_off & 3)) return hipErrorInvalidValue;
+    if (qtiles % 4 == 0 && !mask && (p.ldvT & 7) == 0) hiera_attn_v2_kernel<true><<<dim3(total / 4), dim3(256), 0, stream>>>(p);
+    else if (qtiles % 4 == 0) {
+      if (mask) hiera_attn_kernel<true, true, true><<<dim3(blocks), dim3(256), 0, stream>>>(p);
+      else hiera_attn_kernel<true, false, true><<<dim3(blocks), dim3(256), 0, stream>>>(p);
+    } else {
+      if (mask) hiera_attn_kernel<false, true, true><<<dim3(blocks), dim3(256), 0, stream>>>(p);
+      else hiera_attn_kernel<false, false, true><<<dim3(blocks), dim3(256), 0, stream>>>(p);
+    }
   } else if (qtiles % 4 == 0 && !mask && !use_v1 && (p.ldvT & 7) == 0) {
     hiera_attn_v2_kernel<false><<<dim3(total / 4), dim3(256), 0, stream>>>(p);
   } else if (qtiles % 4 == 0) {

@@ -195,6 +195,34 @@ __global__ void pool_tokens_kernel(const T* __restrict__ in, int ldin, T* __rest
   out[ot * ldout + c] = (T)m;
 }
 
+// the same on a 2-term f16 split (hi plane + lo plane lo_off elements behind it, common.h): the maximum of the four VALUES
+// hi + lo * 2^-11, written as the (hi, lo) pair of the token that holds it (exact: a max-pool selects, it does not compute)
+__global__ void pool_tokens_split_kernel(const half_t* __restrict__ in, size_t in_lo, int ldin, half_t* __restrict__ out, size_t out_lo, int ldout,
+                                         int nwin, int w, int C) {
+  const int hw = w / 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)nwin * hw * hw * C;
+  if (i >= total) return;
+  const int c = (int)(i % C);
+  const size_t ot = i / C;
+  const int win = (int)(ot / (hw * hw)), p = (int)(ot % (hw * hw));
+  const int py = p / hw, px = p % hw;
+  const half_t* base = in + ((size_t)win * w * w) * ldin + c;
+  float m = -3.0e38f;
+  half_t mh = (half_t)0.f, ml = (half_t)0.f;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const half_t* q = base + (size_t)((2 * py + dy) * w + 2 * px + dx) * ldin;
+      const half_t h = q[0], l = q[in_lo];
+      const float v = (float)h + (float)l * SPLIT_INV;
+      if (v > m) { m = v; mh = h; ml = l; }
+    }
+  out[ot * ldout + c] = mh;
+  out[ot * ldout + c + out_lo] = ml;
+}
+
 // ------------------------------------------------------------------ token re-ordering between window sizes
 // 4 channels per thread (C % 4 == 0); frame b of the output goes to dst.p[b] (the feature-cache slots of the frames are not
 // contiguous), or to out + b * H * W * C when dst.p[0] is null.
@@ -318,6 +346,10 @@ hipError_t pool_tokens_f32_launch(const float* in, int ldin, float* out, int ldo
 }
 hipError_t pool_tokens_f16_launch(const half_t* in, int ldin, half_t* out, int ldout, int nwin, int w, int C, hipStream_t s) {
   pool_tokens_kernel<half_t><<<grid1d((size_t)nwin * (w / 2) * (w / 2) * C), dim3(256), 0, s>>>(in, ldin, out, ldout, nwin, w, C);
+  return hipGetLastError();
+}
+hipError_t pool_tokens_split_launch(const half_t* in, size_t in_lo, int ldin, half_t* out, size_t out_lo, int ldout, int nwin, int w, int C, hipStream_t s) {
+  pool_tokens_split_kernel<<<grid1d((size_t)nwin * (w / 2) * (w / 2) * C), dim3(256), 0, s>>>(in, in_lo, ldin, out, out_lo, ldout, nwin, w, C);
   return hipGetLastError();
 }
 hipError_t permute_tokens_launch(const float* in, float* out, int B, int H, int W, int C, int w_in, int w_out,

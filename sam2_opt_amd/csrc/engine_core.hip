@@ -112,7 +112,7 @@ bool xs_eligible(const sam2mi_ctx* ctx, const GemmParams& p) {
   static const int min_k = getenv("SAM2MI_XS_MINK") ? atoi(getenv("SAM2MI_XS_MINK")) : 0;      // A/B aid
   static const int min_m = getenv("SAM2MI_XS_MINM") ? atoi(getenv("SAM2MI_XS_MINM")) : 16384;      // A/B aid: 8192 takes batch-2 encoder calls from 9.67 to 9.27 ms (batch 1, M = 4096: 6.24 -> 6.39), but then a 2-frame and a 1-frame pass of the same frame differ in the last bits
   if (p.w_lo_off) {            // weight split (f16s): the QKV shape only - f16 outputs, no activation, the V^T consumer reads the hi plane
-    if (!p.xs_wpack || p.act != ACT_NONE || p.out32 || p.ln_x32 || (p.outT16 && p.out_lo_off && !p.outT_hi_only)) return false;
+    if (!p.xs_wpack || p.act != ACT_NONE || p.ln_x32 || (p.outT16 && p.out_lo_off && !p.outT_hi_only)) return false;
   } else if (p.out_lo_off || !p.xs_pack) return false;
   return ctx->use_xs && !p.a_lo_off && p.pool_w == 0 && p.K >= min_k && p.tile_hint == 0 && p.M >= min_m && (p.ln_x32 ? p.ln_ld == p.K : p.lda == p.K) && gemm_xs_supported(p.N, p.K) &&
          (p.act == ACT_NONE || p.act == ACT_GELU) && p.rope_cols == 0 && p.res_mod == 0 && !p.outT32 && (p.n_split >= p.N || (p.n_split & 31) == 0) &&
@@ -652,12 +652,14 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
         L->xs_pack = (half_t*)dalloc(ctx, gemm_xs_pack_bytes(L->N, L->K));
         if (!L->xs_pack || gemm_xs_pack(L->w, L->N, L->K, L->K, L->xs_pack, nullptr) != hipSuccess) pk.ok = false;
       }
-      if (pk.ok && ctx->selective && b.qkv.w && b.qkv.lo_off && gemm_xs_supported(b.qkv.N, b.qkv.K) &&
-          ctx->plan[dim_out >= 1152 ? 4 : dim_out >= 576 ? 3 : dim_out >= 288 ? 2 : 1][LIN_QKV] == PREC_WSPLIT) {      // f16s: QKV on the weight-split X-stationary kernel
-        const size_t scratch_b = (size_t)2 * ((b.qkv.N + 31) / 32 * 32) * b.qkv.K * sizeof(half_t);
+      for (int kind : {LIN_QKV, LIN_PROJ}) {       // f16s: the linears planned as weight split also as [W_hi | W_lo] image of the X-stationary kernel
+        Lin16* L = kind == LIN_QKV ? &b.qkv : &b.proj;
+        if (!pk.ok || !ctx->selective || !L->w || !L->lo_off || !gemm_xs_supported(L->N, L->K) ||
+            ctx->plan[dim_out >= 1152 ? 4 : dim_out >= 576 ? 3 : dim_out >= 288 ? 2 : 1][kind] != PREC_WSPLIT) continue;
+        const size_t scratch_b = (size_t)2 * ((L->N + 31) / 32 * 32) * L->K * sizeof(half_t);
         half_t* scratch = (half_t*)dalloc_raw(ctx, scratch_b);
-        b.qkv.xs_wpack = (half_t*)dalloc(ctx, gemm_xs_wsplit_pack_bytes(b.qkv.N, b.qkv.K));
-        if (!scratch || !b.qkv.xs_wpack || gemm_xs_wsplit_pack(b.qkv.w, b.qkv.w + b.qkv.lo_off, b.qkv.N, b.qkv.K, b.qkv.xs_wpack, scratch, nullptr) != hipSuccess) pk.ok = false;
+        L->xs_wpack = (half_t*)dalloc(ctx, gemm_xs_wsplit_pack_bytes(L->N, L->K));
+        if (!scratch || !L->xs_wpack || gemm_xs_wsplit_pack(L->w, L->w + L->lo_off, L->N, L->K, L->xs_wpack, scratch, nullptr) != hipSuccess) pk.ok = false;
         if (scratch) { hipStreamSynchronize(nullptr); dfree(ctx, scratch); }
       }
       // stages 1-2 only by default: at C = 576 a 32-row workgroup streams the whole 663-KB weight from L2 with 9 KB per wave in flight

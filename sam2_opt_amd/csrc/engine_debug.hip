@@ -100,14 +100,14 @@ extern "C" int sam2mi_debug_hiera_attention(sam2mi_ctx* ctx, void* stream, const
   hipStream_t s = (hipStream_t)stream;
   const int C = heads * 72, Mq = groups * GQ, Mk = groups * GK;
   Tmp t;
-  if (ctx->selective && ctx->split_attn && wq >= GQ && wk >= GK && GQ % 128 == 0 && (Mk & 7) == 0) {
-    // f16s context, the shapes of the shared-tile kernel: q / k as hi + lo planes, V^T in f16, output folded back from hi + lo
-    half_t* q16 = t.get<half_t>((size_t)Mq * C * 2);
-    half_t* k16 = t.get<half_t>((size_t)Mk * C * 2);
+  if (ctx->selective && ctx->split_attn && (Mk & 7) == 0) {
+    // f16s context: q / k as hi + lo planes, V^T in f16, output folded back from hi + lo
+    half_t* q16 = t.get<half_t>((size_t)std::max(Mq, Mk) * C * 2);
+    half_t* k16 = t.get<half_t>((size_t)std::max(Mq, Mk) * C * 2);
     half_t* vT = t.get<half_t>((size_t)C * Mk);
-    half_t* o = t.get<half_t>((size_t)Mq * C * 2);
-    if (!q16 || !k16 || !vT || !o || Mq != Mk) return sam2mi_set_error(ctx, __func__, "hipMalloc failed (or GQ != GK)");
-    const size_t lo = (size_t)Mq * C;
+    half_t* o = t.get<half_t>((size_t)std::max(Mq, Mk) * C * 2);
+    if (!q16 || !k16 || !vT || !o) return sam2mi_set_error(ctx, __func__, "hipMalloc failed");
+    const size_t lo = (size_t)std::max(Mq, Mk) * C;      // one plane distance for q and k (the kernel takes one qk_lo_off)
     CHK(cast_add_launch(q, C, q, C, 0, 1.4426950408889634f / sqrtf(72.f) - 1.f, Mq, C, q16, C, nullptr, 0, s, lo));   // pre-scaled q
     CHK(cast_add_launch(k, C, nullptr, 0, 0, 0.f, Mk, C, k16, C, nullptr, 0, s, lo));
     transpose_to_f16_kernel<<<dim3((unsigned)(((size_t)Mk * C + 255) / 256)), dim3(256), 0, s>>>(v, vT, Mk, C, Mk);
@@ -118,7 +118,7 @@ extern "C" int sam2mi_debug_hiera_attention(sam2mi_ctx* ctx, void* stream, const
     a.GQ = GQ; a.GK = GK; a.wq = wq; a.wk = wk; a.num_groups = groups; a.scale_log2e = 1.4426950408889634f / sqrtf(72.f);
     a.qk_lo_off = lo; a.o_lo_off = lo;
     CHKI(run_hiera_attn(ctx, s, a));
-    split_to_f32_kernel<<<dim3((unsigned)(((size_t)Mq * C + 255) / 256)), dim3(256), 0, s>>>(o, lo, out, lo);
+    split_to_f32_kernel<<<dim3((unsigned)(((size_t)Mq * C + 255) / 256)), dim3(256), 0, s>>>(o, lo, out, (size_t)Mq * C);
     CHK(hipGetLastError());
     CHK(hipStreamSynchronize(s));
     return 0;

@@ -56,10 +56,8 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
       CHK(pool_tokens_f32_launch(ctx->ws_x2, Co, x, Co, M / (wcur * wcur), wcur, Co, s));
     }
   }
-  // f16s: the shapes of the shared-tile attention kernel (stage-3 windows, global blocks) take q / k as f16 hi + lo planes and
-  // V^T as plain f16 (attn_hiera.hip, SPLIT); the others (pooled queries, packed small windows) stay on attn_precise.hip
-  const int win_n = b.window > 0 ? wcur * wcur : H * W;
-  const bool split_attn = ctx->selective && ctx->split_attn && !b.q_pool && (win_n % 128) == 0 && (M & 7) == 0;
+  // f16s: attention takes q / k as f16 hi + lo planes (three products for the scores) and V^T as plain f16 (attn_hiera.hip, SPLIT)
+  const bool split_attn = ctx->selective && ctx->split_attn && (M & 7) == 0;
   // 2. QKV projection: q|k row-major, v transposed (attention consumes V^T tiles)
   {
     GemmParams p = qkv_p;
@@ -123,7 +121,8 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
     }
   } else {
     // Q max-pooled inside each window (hieradet.py:64-67)
-    CHK(pool_tokens_f16_launch(ctx->ws_qk16, 2 * Co, ctx->ws_qp16, Co, M / (wcur * wcur), wcur, Co, s));
+    if (split_attn) CHK(pool_tokens_split_launch(ctx->ws_qk16, ctx->lo16, 2 * Co, ctx->ws_qp16, ctx->lo16, Co, M / (wcur * wcur), wcur, Co, s));
+    else CHK(pool_tokens_f16_launch(ctx->ws_qk16, 2 * Co, ctx->ws_qp16, Co, M / (wcur * wcur), wcur, Co, s));
     a.q = ctx->ws_qp16; a.ldq = Co;
     const int nk = wcur * wcur, nq = nk / 4;
     if (nq >= 32) { a.GQ = nq; a.GK = nk; a.wq = nq; a.wk = nk; a.num_groups = M / nk; }

@@ -25,7 +25,7 @@ struct GemmXsParams {
   // the row; the weight / bias must carry the affine part (Lin16::xs_ln_pack).  ldx32 % 4 == 0.
   const float* ln_x32; int ldx32; float ln_eps;
   // weight split (f16s precision mode): wpack is the image of gemm_xs_wsplit_pack ([W_hi | W_lo] chunk pairs), two MFMA chains per
-  // output tile; f16 outputs without activation only.  out_lo_off != 0: out16 is written as hi + lo planes (outT16: hi only)
+  // output tile; no activation.  out_lo_off != 0: out16 is written as hi + lo planes (outT16: hi only)
   int wsplit; size_t out_lo_off;
 };
 bool gemm_xs_supported(int N, int K);

@@ -328,8 +328,9 @@ hipError_t launch_k(const GemmXsParams& p, hipStream_t s) {
     splits = std::max(1, std::min(splits, groups));
     if ((groups + splits - 1) / splits > max_groups) return hipErrorInvalidValue;
     const dim3 grid(tb, splits), block(64 * NW);
-    if (p.out32 || p.act != ACT_NONE) return hipErrorInvalidValue;      // f16 outputs, no activation: the QKV projections
-    gemm_xs_kernel<K, false, false, 0, true><<<grid, block, LDS_B, s>>>(p);
+    if (p.act != ACT_NONE) return hipErrorInvalidValue;      // no activation: the QKV (f16 out) and output (f32 out + residual) projections
+    if (p.out32) gemm_xs_kernel<K, false, true, 0, true><<<grid, block, LDS_B, s>>>(p);
+    else gemm_xs_kernel<K, false, false, 0, true><<<grid, block, LDS_B, s>>>(p);
     return hipGetLastError();
   }
   const int nstages = (p.N + 32 * CPS - 1) / (32 * CPS);
@@ -364,6 +365,7 @@ hipError_t attr_k() {
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, false, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, false, false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_xs_kernel<K, false, true, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
   return e;
 }
 }  // namespace

@@ -109,20 +109,24 @@ def test_gemm_xs_weight_split(engs, M, N, K):
     check(f"gemm_xs wsplit {M}x{N}x{K}", out, ref.float(), 1e-5, 3e-6)
 
 
-@pytest.mark.parametrize("groups,heads,GQ,GK", [(2, 8, 256, 256), (9, 8, 256, 256), (1, 8, 1024, 1024), (2, 8, 4096, 4096), (3, 2, 128, 128)])
-def test_split_qk_attention(engs, groups, heads, GQ, GK):
-    """hiera_attn_v2_kernel<SPLIT> (stage-3 windows and global blocks of the f16s mode): q / k as 2-term f16 splits (three products
+@pytest.mark.parametrize("groups,heads,GQ,GK,wq,wk", [
+    (2, 8, 256, 256, 256, 256), (9, 8, 256, 256, 256, 256), (1, 8, 1024, 1024, 1024, 1024), (2, 8, 4096, 4096, 4096, 4096), (3, 2, 128, 128, 128, 128),
+    (6, 2, 64, 64, 64, 64), (5, 4, 32, 128, 16, 64), (9, 4, 32, 32, 16, 16), (3, 8, 32, 128, 4, 16), (2, 16, 64, 256, 64, 256),
+])
+def test_split_qk_attention(engs, groups, heads, GQ, GK, wq, wk):
+    """hiera_attn_v2_kernel<SPLIT> (stage-3 windows, global blocks) and hiera_attn_kernel<.., SPLIT> (packed small windows, pooled
+    queries) of the f16s mode, on every grouping the trunk uses: q / k as 2-term f16 splits (three products
     for the scores), p and v in f16.  Unrounded q / k, f16-rounded v; a spiked key makes the running maximum jump late in the sweep.
     With f16 q / k the same inputs give 3e-4 (test_hiera_attention's tolerance is 4e-3); here the f16 probabilities are what is left."""
     g = torch.Generator(device="cpu").manual_seed(groups * 100 + GQ + GK + 1)
     C = heads * 72
     q = (torch.randn(groups * GQ, C, generator=g) * 1.5)
     k = (torch.randn(groups * GK, C, generator=g) * 1.5)
-    k[GK - 3, :72] = q[5, :72] * 1.5
+    k[wk - 3, :72] = q[5, :72] * 1.5
     v = torch.randn(groups * GK, C, generator=g).half().float()
-    out = engs.debug_hiera_attention(q.cuda(), k.cuda(), v.cuda(), groups, heads, GQ, GK, GQ, GK)
-    ref = _ref_attn(q.cuda(), k.cuda(), v.cuda(), groups, heads, GQ, GK, GQ, GK)
-    check(f"split_qk_attn g{groups} h{heads} {GQ}/{GK}", out, ref, 1e-3, 3e-4)
+    out = engs.debug_hiera_attention(q.cuda(), k.cuda(), v.cuda(), groups, heads, GQ, GK, wq, wk)
+    ref = _ref_attn(q.cuda(), k.cuda(), v.cuda(), groups, heads, GQ, GK, wq, wk)
+    check(f"split_qk_attn g{groups} h{heads} {GQ}/{GK} w{wq}/{wk}", out, ref, 1e-3, 3e-4)
 
 
 # ----------------------------------------------------------------------------- plugs vs the oracle
