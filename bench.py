@@ -20,8 +20,16 @@ The JSON line also carries
   cpu_baseline - the CPU oracle (oracle/sam2_ref.py, a port of the reference's torch backend) timed on this
                  box's host cores on the first 16 frames of the same clip; value = STEADY-STATE frames/s over frames 8..15
                  (memory bank full: L = 7), the plan of BASELINE.md 3 (rank 0, N = 1 only);
-  secondary    - (N = 1) fps of the same clip in the f16x3 precision mode (the "masks within 1e-3" class) and images/s of
+  parity       - the timed precision mode against the REAL reference's 24-frame golden (tests/golden/large_video24_full.npz: every
+                 low-res pixel of every frame), measured by this run on the bench configuration (encode_batch, prefetch stream):
+                 max-abs / max|ref|, relative L2, binarised-pixel disagreement, worst frame; `parity_class` = the bar it is held to;
+  secondary    - (N = 1) the same clip in the other precision modes - "f16" (plain f16 operands, the bf16-class parity tier) with
+                 its own roofline and parity objects, "f16x3" (every operand split) - the drop-in route, and images/s of
                  BASELINE.json configs[4] (16 images x 8 point prompts, one encoder call).
+
+Precision modes (sam2mi_config.precision): the default timed mode is "f16s" - f16 MFMA operands with a SELECTIVE
+2-term split of the operands whose rounding carries the error - because it is the fastest mode that meets the north-star bar
+"masks within 1e-3 of the reference"; "f16" is faster and sits at 2e-3.
 
 `--backend gloo --stub-predictor` runs the SAME orchestration (rank / world from the environment, process-group init, warm-up,
 barrier, timed steps, MAX-over-ranks reduction, result gather, the JSON line) on the CPU with a stand-in predictor: that is how
@@ -109,29 +117,150 @@ def stub_main(args, rank, world):
         dist.destroy_process_group()
 
 
-def secondary_legs(args, pred, sd, cfg, frames, device):
-    """(a) the same clip in the other precision mode, (b) BASELINE.json configs[4]: 16 images x 8 point prompts."""
-    from sam2_opt_amd.image_predictor import SAM2ImagePredictor
+def roofline_pass(args, pred, one_step, steps, dt):
+    """Second, un-timed pass of the same `steps` steps with HIP events around every launch (sam2mi_profile_enable) -> the roofline
+    object of the JSON line.  `dt` = wall time of the timed steps (for the shares)."""
+    # per-launch kernel durations (HIP events on the launch stream): measured with the encoder prefetch stream off, so
+    # that every kernel runs alone on the chip as it does under rocprofv3 --kernel-trace (profiles/)
+    torch.cuda.synchronize()
+    overlap, pred.overlap_encode = pred.overlap_encode, False
+    pred.engine.profile_enable(True)
+    for _ in range(steps):
+        one_step()
+    torch.cuda.synchronize()
+    pr = pred.engine.profile_read()
+    pred.engine.profile_enable(False)
+    pred.overlap_encode = overlap
+    # The MFMA GEMM work of the path runs in three hand-written kernel families (tiled gemm_v2_kernel, X-stationary
+    # gemm_xs_kernel, fused-MLP mlp_fused_kernel).  The roofline object is the kernel INSTANTIATION that takes the most time,
+    # under the name rocprofv3 prints for it, so that its average launch duration can be checked against profiles/*_kernel_stats.csv;
+    # the other instantiations and the family totals are listed beside it, all measured in the same pass.
+    what = {"gemm_v2_kernel": "tiled LDS-DMA GEMM: projections, fc2, stage 4, neck, tracking path",
+            "gemm_xs_kernel": "X-stationary short-K GEMM: QKV of stages 1-3, fc1 of stage 3",
+            "mlp_fused_kernel": "fused fc1+GELU+fc2+residual of stages 1-2", "gemm_ks_kernel": "accumulator-stationary N=576 GEMM (opt-in)"}
+    kern = {}
+    for name, v in pred.engine.profile_read_kernels().items():
+        if v["launches"] == 0 or v["ms"] <= 0:
+            continue
+        tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
+        gbps = v["bytes"] / (v["ms"] * 1e-3) / 1e9                       # ALGORITHMIC bytes / launch time
+        ai = v["flops"] / max(v["bytes"], 1.0)
+        # which roof is the lower one for this kernel's arithmetic intensity: min(peak MFMA, AI * peak HBM)
+        bound = "hbm" if ai * PEAK_HBM_GBPS * 1e9 < PEAK_F16_TFLOPS * 1e12 else "mfma"
+        kern[name] = {"bound": bound, "achieved": round(tf, 2), "frac": round(tf / PEAK_F16_TFLOPS, 4), "hbm_gbps": round(gbps, 1),
+                      "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4), "flop_per_byte": round(ai, 1), "launches": v["launches"],
+                      "gflop_per_launch": round(v["flops"] / v["launches"] / 1e9, 3), "mb_per_launch": round(v["bytes"] / v["launches"] / 1e6, 1),
+                      "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2), "share_of_timed_region": round(v["ms"] * 1e-3 / dt, 3)}
+    dom = max(kern, key=lambda k: kern[k]["share_of_timed_region"])
+    fams = {}
+    for fam, key in (("gemm_v2_kernel", "gemm"), ("gemm_xs_kernel", "xs"), ("mlp_fused_kernel", "mlp"), ("gemm_ks_kernel", "ks")):
+        ms, fl, n = pr[f"{key}_ms"], pr[f"{key}_flops"], int(pr[f"{key}_launches"])
+        if n:
+            fams[fam] = {"what": what[fam], "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "launches": n,
+                         "share_of_timed_region": round(ms * 1e-3 / dt, 3)}
+    tot_ms = sum(pr[f"{k}_ms"] for k in ("gemm", "xs", "mlp", "ks"))
+    tot_fl = sum(pr[f"{k}_flops"] for k in ("gemm", "xs", "mlp", "ks"))
+    # the dominant kernel against the roof that bounds it: "hbm" when its algorithmic intensity lies under the ridge
+    # (312 FLOP/B) - achieved = algorithmic GB/s of 8,000 - else "mfma" - achieved = TFLOP/s of 2,500; the other fraction beside it
+    d = kern[dom]
+    hbm = d["bound"] == "hbm"
+    roofline = {
+        "bound": d["bound"], "kernel": dom, "achieved": d["hbm_gbps"] if hbm else d["achieved"], "peak": PEAK_HBM_GBPS if hbm else PEAK_F16_TFLOPS,
+        "unit": "GB/s" if hbm else "TFLOP/s", "frac": d["hbm_frac"] if hbm else d["frac"], "traffic": _pmc_traffic(dom),
+        "mfma": {"achieved": d["achieved"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": d["frac"]},
+        "hbm": {"achieved": d["hbm_gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": d["hbm_frac"], "flop_per_byte": d["flop_per_byte"],
+                "algorithmic_mb_per_launch": d["mb_per_launch"]},
+        "launches": kern[dom]["launches"], "gflop_per_launch": kern[dom]["gflop_per_launch"], "avg_launch_us": kern[dom]["avg_launch_us"],
+        "share_of_timed_region": kern[dom]["share_of_timed_region"],
+        "kernels": dict(sorted(kern.items(), key=lambda kv: -kv[1]["share_of_timed_region"])),
+        "families": fams,
+        "all_gemm_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
+                             "share_of_timed_region": round(tot_ms * 1e-3 / dt, 3)},
+        "attention_kernels": {"achieved": round(pr["attn_flops"] / max(pr["attn_ms"] * 1e-3, 1e-9) / 1e12, 2),
+                              "launches": int(pr["attn_launches"]), "ms": round(pr["attn_ms"], 2)},
+        "whole_path": {"algorithmic_gflop_per_step": CLIP_GFLOP_PROPAGATE * args.frames / 100.0,
+                       "achieved_tflops": round(CLIP_GFLOP_PROPAGATE * args.frames / 100.0 * steps / 1e3 / dt, 2)},
+    }
+    roofline["whole_path"]["frac_of_mfma_peak"] = round(roofline["whole_path"]["achieved_tflops"] / PEAK_F16_TFLOPS, 4)
+
+    return roofline
+
+
+def parity_leg(args, sd, cfg, device, precision):
+    """The 24-frame clip of tests/golden/large_video24_full.npz (seed 2, one click; recorded from the real reference by
+    oracle/gen_golden.py) through the predictor in the bench configuration: worst-frame metrics over every low-res pixel."""
+    from sam2_opt_amd.synthetic import normalize_frames, synthetic_frames_u8
     from sam2_opt_amd.video_predictor import SAM2VideoPredictor
-    out = {}
-    other = "f16x3" if args.precision == "f16" else "f16"
-    p2 = SAM2VideoPredictor("large", state_dict=sd, encode_batch=args.encode_batch, device=device, overlap_encode=not args.no_overlap, precision=other)
+    path = os.path.join(ROOT, "tests", "golden", "large_video24_full.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    T = int(g["num_frames"][0])
+    frames = normalize_frames(synthetic_frames_u8(seed=2, num_frames=T), cfg)
+    pred = SAM2VideoPredictor("large", state_dict=sd, encode_batch=args.encode_batch, device=device, overlap_encode=not args.no_overlap, precision=precision)
+    try:
+        st = pred.init_state(frames=frames, video_height=1024, video_width=1024)
+        pred.add_new_points_or_box(st, 0, 1, points=np.array([[512.0, 512.0]], np.float32), labels=np.array([1], np.int32))
+        worst = [0.0, 0.0, 0.0]
+        for t, _ids, _vm in pred.propagate_in_video(st):
+            od = st["output_dict_per_obj"][0]
+            cur = od["cond_frame_outputs"].get(t) or od["non_cond_frame_outputs"][t]
+            got, ref = cur["pred_masks"].float().cpu().numpy(), g[f"f{t}/pred_masks"]
+            d = got - ref
+            worst[0] = max(worst[0], float(np.abs(d).max() / np.abs(ref).max()))
+            worst[1] = max(worst[1], float(np.linalg.norm(d) / np.linalg.norm(ref)))
+            worst[2] = max(worst[2], float(((got > 0) != (ref > 0)).mean()))
+        return {"vs": "real reference (fp32 torch backend), tests/golden/large_video24_full.npz", "frames": T, "pixels_per_frame": 65536,
+                "max_abs_over_max_ref": float(f"{worst[0]:.3e}"), "rel_l2": float(f"{worst[1]:.3e}"), "binarised_disagreement": float(f"{worst[2]:.3e}"),
+                "within_1e-3": bool(max(worst) <= 1e-3)}
+    finally:
+        pred.release()
+
+
+PARITY_CLASS = {"f16s": "masks within 1e-3 of the reference fp32 path (north star)", "f16x3": "masks within 1e-3 of the reference fp32 path (north star)",
+                "f16": "bf16-class tier: ~2e-3 of the reference fp32 path (outside the north-star 1e-3)"}
+
+
+def mode_leg(args, sd, cfg, frames, device, precision, steps, with_roofline):
+    """One more precision mode on the same clip and method: 1 warm-up + `steps` timed steps, then the same roofline pass and parity
+    leg as the headline mode."""
+    from sam2_opt_amd.video_predictor import SAM2VideoPredictor
+    p2 = SAM2VideoPredictor("large", state_dict=sd, encode_batch=args.encode_batch, device=device, overlap_encode=not args.no_overlap, precision=precision,
+                            prefetch_depth=args.prefetch_depth)
     try:
         st = p2.init_state(frames=frames, video_height=1024, video_width=1024)
         p2.add_new_points_or_box(st, 0, 1, points=np.array([[512.0, 512.0]], np.float32), labels=np.array([1], np.int32))
-        steps = 2
-        for k in range(1 + steps):
-            if k == 1:
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-            n = sum(1 for _ in p2.propagate_in_video(st))
+
+        def one_step():
+            n = 0
+            for _ in p2.propagate_in_video(st):
+                n += 1
+            return n, None
+        one_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for _ in range(steps):
+            n += one_step()[0]
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        out[f"{other}_frames_per_s"] = round(steps * n / dt, 2)
-        out[f"{other}_note"] = (f"same clip and method, precision={other}, 1 warm-up + {steps} timed steps; "
-                                "f16x3 = split-f16 MFMA operands (3 MFMAs per product), masks within 1e-3 of the reference (measured ~5e-6)")
+        out = {"frames_per_s": round(n / dt, 2), "ms_per_frame": round(dt / n * 1e3, 3), "steps": steps, "dtype": "f16", "precision_mode": precision,
+               "parity_class": PARITY_CLASS[precision]}
+        if with_roofline:
+            out["roofline"] = roofline_pass(args, p2, one_step, steps, dt)
+        out["parity"] = parity_leg(args, sd, cfg, device, precision)
+        return out
     finally:
         p2.release()
+
+
+def secondary_legs(args, pred, sd, cfg, frames, device):
+    """(a) the same clip in the other precision modes, (b) the drop-in route, (c) BASELINE.json configs[4]: 16 images x 8 point prompts."""
+    from sam2_opt_amd.image_predictor import SAM2ImagePredictor
+    out = {}
+    for other in ("f16s", "f16", "f16x3"):
+        if other != args.precision:
+            out[other] = mode_leg(args, sd, cfg, frames, device, other, 2, with_roofline=(other != "f16x3") and not args.no_roofline)
     # (c) route A: the drop-in route - a torch host loop around the five plug-level entry points in the reference's tensor
     # layouts (sam2_opt_amd/route_a.py), what sam2_opt_amd.plugin.speedup_hip(reference_predictor) pays per frame
     from sam2_opt_amd.route_a import PlugLevelTracker
@@ -223,8 +352,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the clip timed on the CPU oracle (steady state = frames 8..)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads of the baseline leg (reported as `cores`)")
-    ap.add_argument("--precision", default="f16", choices=("f16", "f16x3", "f16s"), help="precision mode of the timed run")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the f16x3 / config-5 secondary measurements")
+    ap.add_argument("--precision", default="f16s", choices=("f16", "f16x3", "f16s"),
+                    help="precision mode of the timed run (default: the fastest one inside the north-star 1e-3 bar)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the parity leg, the other precision modes, the drop-in route and config 5")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"))
     ap.add_argument("--stub-predictor", action="store_true", help="CPU stand-in predictor (orchestration tests only; never a result)")
     args = ap.parse_args()
@@ -277,68 +407,8 @@ def main():
 
     roofline = None
     if not args.no_roofline and rank == 0:
-        # per-launch kernel durations (HIP events on the launch stream): measured with the encoder prefetch stream off, so
-        # that every kernel runs alone on the chip as it does under rocprofv3 --kernel-trace (profiles/)
-        torch.cuda.synchronize()
-        overlap, pred.overlap_encode = pred.overlap_encode, False
-        pred.engine.profile_enable(True)
-        for _ in range(args.steps):
-            one_step()
-        torch.cuda.synchronize()
-        pr = pred.engine.profile_read()
-        pred.engine.profile_enable(False)
-        pred.overlap_encode = overlap
-        # The MFMA GEMM work of the path runs in three hand-written kernel families (tiled gemm_v2_kernel, X-stationary
-        # gemm_xs_kernel, fused-MLP mlp_fused_kernel).  The roofline object is the kernel INSTANTIATION that takes the most time,
-        # under the name rocprofv3 prints for it, so that its average launch duration can be checked against profiles/*_kernel_stats.csv;
-        # the other instantiations and the family totals are listed beside it, all measured in the same pass.
-        what = {"gemm_v2_kernel": "tiled LDS-DMA GEMM: projections, fc2, stage 4, neck, tracking path",
-                "gemm_xs_kernel": "X-stationary short-K GEMM: QKV of stages 1-3, fc1 of stage 3",
-                "mlp_fused_kernel": "fused fc1+GELU+fc2+residual of stages 1-2", "gemm_ks_kernel": "accumulator-stationary N=576 GEMM (opt-in)"}
-        kern = {}
-        for name, v in pred.engine.profile_read_kernels().items():
-            if v["launches"] == 0 or v["ms"] <= 0:
-                continue
-            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
-            gbps = v["bytes"] / (v["ms"] * 1e-3) / 1e9                       # ALGORITHMIC bytes / launch time
-            ai = v["flops"] / max(v["bytes"], 1.0)
-            # which roof is the lower one for this kernel's arithmetic intensity: min(peak MFMA, AI * peak HBM)
-            bound = "hbm" if ai * PEAK_HBM_GBPS * 1e9 < PEAK_F16_TFLOPS * 1e12 else "mfma"
-            kern[name] = {"bound": bound, "achieved": round(tf, 2), "frac": round(tf / PEAK_F16_TFLOPS, 4), "hbm_gbps": round(gbps, 1),
-                          "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4), "flop_per_byte": round(ai, 1), "launches": v["launches"],
-                          "gflop_per_launch": round(v["flops"] / v["launches"] / 1e9, 3), "mb_per_launch": round(v["bytes"] / v["launches"] / 1e6, 1),
-                          "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2), "share_of_timed_region": round(v["ms"] * 1e-3 / dt, 3)}
-        dom = max(kern, key=lambda k: kern[k]["share_of_timed_region"])
-        fams = {}
-        for fam, key in (("gemm_v2_kernel", "gemm"), ("gemm_xs_kernel", "xs"), ("mlp_fused_kernel", "mlp"), ("gemm_ks_kernel", "ks")):
-            ms, fl, n = pr[f"{key}_ms"], pr[f"{key}_flops"], int(pr[f"{key}_launches"])
-            if n:
-                fams[fam] = {"what": what[fam], "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "launches": n,
-                             "share_of_timed_region": round(ms * 1e-3 / dt, 3)}
-        tot_ms = sum(pr[f"{k}_ms"] for k in ("gemm", "xs", "mlp", "ks"))
-        tot_fl = sum(pr[f"{k}_flops"] for k in ("gemm", "xs", "mlp", "ks"))
-        # the dominant kernel against the roof that bounds it: "hbm" when its algorithmic intensity lies under the ridge
-        # (312 FLOP/B) - achieved = algorithmic GB/s of 8,000 - else "mfma" - achieved = TFLOP/s of 2,500; the other fraction beside it
-        d = kern[dom]
-        hbm = d["bound"] == "hbm"
-        roofline = {
-            "bound": d["bound"], "kernel": dom, "achieved": d["hbm_gbps"] if hbm else d["achieved"], "peak": PEAK_HBM_GBPS if hbm else PEAK_F16_TFLOPS,
-            "unit": "GB/s" if hbm else "TFLOP/s", "frac": d["hbm_frac"] if hbm else d["frac"], "traffic": _pmc_traffic(dom),
-            "mfma": {"achieved": d["achieved"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": d["frac"]},
-            "hbm": {"achieved": d["hbm_gbps"], "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": d["hbm_frac"], "flop_per_byte": d["flop_per_byte"],
-                    "algorithmic_mb_per_launch": d["mb_per_launch"]},
-            "launches": kern[dom]["launches"], "gflop_per_launch": kern[dom]["gflop_per_launch"], "avg_launch_us": kern[dom]["avg_launch_us"],
-            "share_of_timed_region": kern[dom]["share_of_timed_region"],
-            "kernels": dict(sorted(kern.items(), key=lambda kv: -kv[1]["share_of_timed_region"])),
-            "families": fams,
-            "all_gemm_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
-                                 "share_of_timed_region": round(tot_ms * 1e-3 / dt, 3)},
-            "attention_kernels": {"achieved": round(pr["attn_flops"] / max(pr["attn_ms"] * 1e-3, 1e-9) / 1e12, 2),
-                                  "launches": int(pr["attn_launches"]), "ms": round(pr["attn_ms"], 2)},
-            "whole_path": {"algorithmic_gflop_per_step": CLIP_GFLOP_PROPAGATE * args.frames / 100.0,
-                           "achieved_tflops": round(CLIP_GFLOP_PROPAGATE * args.frames / 100.0 * args.steps / 1e3 / dt, 2)},
-        }
-        roofline["whole_path"]["frac_of_mfma_peak"] = round(roofline["whole_path"]["achieved_tflops"] / PEAK_F16_TFLOPS, 4)
+        roofline = roofline_pass(args, pred, one_step, args.steps, dt)
+    parity = parity_leg(args, sd, cfg, device, args.precision) if (rank == 0 and world == 1 and not args.no_secondary) else None
 
     secondary = None
     if not args.no_secondary and rank == 0 and world == 1:
@@ -352,12 +422,12 @@ def main():
         out = {
             "metric": "frames/sec SAM2.1-hiera-large 1024x1024 video propagation", "value": round(value, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "precision_mode": args.precision, "parity_class": PARITY_CLASS[args.precision], "data": "synthetic",
             "config": {"workload": f"config3: {args.frames}-frame 1024x1024 clip per GPU, 1 click, 1 object, SAM2.1-hiera-large "
                                    "(random-init weights), propagate_in_video loop", "frames_per_step": args.frames,
                        "encode_batch": args.encode_batch, "overlap_encode_stream": not args.no_overlap, "parallelism": f"clips x{world} (one process per GPU)",
                        "ms_per_frame": round(dt / max(nframes, 1) * 1e3, 3), "mask_checksum": round(checksum, 6), "per_rank": records},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "secondary": secondary,
+            "roofline": roofline, "parity": parity, "cpu_baseline": cpu_baseline, "secondary": secondary,
             "library": {"source_hash": _lib_hash()},
         }
         print(json.dumps(out), flush=True)

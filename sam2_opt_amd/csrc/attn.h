@@ -18,6 +18,7 @@ struct HieraAttnParams {
   size_t qk_lo_off, o_lo_off;
 };
 hipError_t hiera_attn_launch(const HieraAttnParams& p, hipStream_t stream);
+const char* hiera_attn_kernel_name(const HieraAttnParams& p);
 
 // ---- head_dim-72 attention of the f16x3 precision mode (attn_precise.hip): same grouping / masking as HieraAttnParams, but
 // q, k, V^T arrive as f32 (the QKV GEMM's f32 outputs) and are split into hi + lo f16 MFMA operands in registers:

@@ -460,6 +460,19 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 3) void hiera_attn_v2_kernel(const
 }
 }  // namespace
 
+// the instantiation hiera_attn_launch picks for these parameters, under the name rocprofv3 prints (profiling accumulators)
+const char* hiera_attn_kernel_name(const HieraAttnParams& p) {
+  const int qtiles = p.GQ / 32;
+  const bool mask = !(p.wq >= p.GQ && p.wk >= p.GK);
+  static const bool use_v1 = getenv("SAM2MI_HATTN_V1") != nullptr;
+  const bool split = p.qk_lo_off != 0;
+  if (qtiles % 4 == 0 && !mask && (split || !use_v1) && (p.ldvT & 7) == 0) return split ? "hiera_attn_v2_kernel<true>" : "hiera_attn_v2_kernel<false>";
+  if (qtiles % 4 == 0) return mask ? (split ? "hiera_attn_kernel<true, true, true>" : "hiera_attn_kernel<true, true, false>")
+                                   : (split ? "hiera_attn_kernel<true, false, true>" : "hiera_attn_kernel<true, false, false>");
+  return mask ? (split ? "hiera_attn_kernel<false, true, true>" : "hiera_attn_kernel<false, true, false>")
+              : (split ? "hiera_attn_kernel<false, false, true>" : "hiera_attn_kernel<false, false, false>");
+}
+
 hipError_t hiera_attn_launch(const HieraAttnParams& p, hipStream_t stream) {
   if (p.GQ % 32 || p.GK % 32 || p.num_groups <= 0) return hipErrorInvalidValue;
   if ((p.ldq & 7) || (p.ldk & 7) || (p.ldvT & 3) || (p.ldo & 3)) return hipErrorInvalidValue;

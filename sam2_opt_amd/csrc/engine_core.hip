@@ -199,7 +199,10 @@ int run_hiera_attn(sam2mi_ctx* ctx, hipStream_t s, const HieraAttnParams& p) {
   CHK(hiera_attn_launch(p, s));
   // algorithmic flops: 4 * Nq * Nk_visible * 72 per head
   const double nk_vis = (p.wq >= p.GQ) ? p.GK : p.wk;
-  if (ctx->prof_on) prof_end(ctx, ctx->prof_attn, s, e0, e1, 4.0 * p.num_groups * (double)p.GQ * nk_vis * 72.0 * p.heads);
+  // algorithmic bytes: q, k (two planes each in the split mode), V^T in, the output (hi + lo in the split mode) out - all f16
+  const double cols = 72.0 * p.heads, planes = p.qk_lo_off ? 2.0 : 1.0;
+  const double bytes = 2.0 * p.num_groups * cols * (planes * (p.GQ + p.GK) + p.GK + (p.o_lo_off ? 2.0 : 1.0) * p.GQ);
+  if (ctx->prof_on) prof_end_named(ctx, ctx->prof_attn, hiera_attn_kernel_name(p), s, e0, e1, 4.0 * p.num_groups * (double)p.GQ * nk_vis * 72.0 * p.heads, bytes);
   return 0;
 }
 int run_precise_attn(sam2mi_ctx* ctx, hipStream_t s, const PreciseAttnParams& p) {
@@ -237,7 +240,9 @@ int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p) {
   hipEvent_t e0, e1;
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_attn, s, e0, e1);
   CHK(flash256_launch(p, s));
-  if (ctx->prof_on) prof_end(ctx, ctx->prof_attn, s, e0, e1, 4.0 * p.Nq * (double)p.Nk * 256.0);
+  // algorithmic bytes: q, K, V^T in (f16), the un-normalised f32 partial outputs + their (max, sum) pairs out (one set per KV split)
+  if (ctx->prof_on) prof_end_named(ctx, ctx->prof_attn, (p.Nk % 32) ? "flash256_v3_kernel<0, true, 4>" : "flash256_v3_kernel<0, false, 4>", s, e0, e1,
+                                   4.0 * p.Nq * (double)p.Nk * 256.0, 512.0 * (p.Nq + 2.0 * p.Nk) + (double)p.splits * p.Nq * (256.0 * 4 + 8));
   return 0;
 }
 
