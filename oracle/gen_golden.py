@@ -2,7 +2,7 @@
 from /root/reference on seeded synthetic inputs and weights.  Container-only; the
 outputs (data, not code) are committed and travel to the GPU box.
 
-    python -m oracle.gen_golden [plugs] [video] [tiny] [interact] [reverse] [multi] [box] [long] [opts] [ingest] [sizes]
+    python -m oracle.gen_golden [plugs] [video] [tiny] [interact] [reverse] [multi] [box] [long] [opts] [ingest] [sizes] [outliers]
 
 Weights: sam2_opt_amd.weights.synthetic_state_dict(cfg, seed=0)   (regenerated anywhere)
 Inputs : sam2_opt_amd.synthetic.*  with the seeds named below.
@@ -90,6 +90,36 @@ def gen_plugs():
             pack(store, f"samheads_mm{int(mm)}/{n}", t, 16384)
     np.savez_compressed(os.path.join(GOLD, "large_plugs.npz"), **store)
     print("plugs done", time.time() - t0)
+
+
+OUTLIER_GAIN = 64.0
+
+
+@torch.inference_mode()
+def gen_outliers():
+    """Outlier-channel scenario (tests/golden/large_outliers.npz): synthetic weights with the LayerNorm gain of three channels x 64
+    in every norm of the trunk and of the memory attention, recurrent damping off - the image encoder on the seeded image and one
+    memory-attention call (L = 3, P = 12) of the REAL reference.  The f16-range check of the HIP modes hangs on it."""
+    cfg = get_config("large")
+    sd = synthetic_state_dict(cfg, seed=0, undamped=True, outlier_gain=OUTLIER_GAIN)
+    model = build_reference_model(cfg, "video", sd)
+    store = {}
+    img = synthetic_image_normed(seed=1)
+    stats = {}
+    blk = model.image_encoder.trunk.blocks[20]
+    h = blk.norm1.register_forward_hook(lambda m, a, o: stats.__setitem__("ln", o.detach().abs().amax(dim=(0, 1, 2))))
+    outs = model.inference_image_torch(img)
+    h.remove()
+    for n, o in zip(["vision_features", "vision_pos_enc0", "vision_pos_enc1", "vision_pos_enc2", "backbone_fpn0", "backbone_fpn1", "backbone_fpn2"], outs):
+        if not n.startswith("vision_pos"):
+            pack(store, "enc/" + n, o, 65536)
+    ln = stats["ln"]
+    store["enc/block20_norm1_absmax_outlier_vs_median"] = np.array([float(ln[list((3, 41, 77))].max()), float(ln.median())], np.float64)
+    pin = plug_inputs(cfg)
+    o = model.memory_attention.inference_memory_attention_torch(*pin["memattn_L3P12"])
+    pack(store, "memattn_L3P12", o, 65536)
+    np.savez_compressed(os.path.join(GOLD, "large_outliers.npz"), **store)
+    print("outliers done", {k: v for k, v in store.items() if "absmax" in k})
 
 
 @torch.inference_mode()
@@ -483,3 +513,5 @@ if __name__ == "__main__":
         gen_ingest()
     if "sizes" in which:
         gen_sizes()
+    if "outliers" in which:
+        gen_outliers()

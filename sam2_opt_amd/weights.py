@@ -234,8 +234,14 @@ def synthetic_tensor(key: str, shape: tuple, seed: int = 0) -> np.ndarray:
     return np.ascontiguousarray(w, dtype=np.float32)
 
 
-def synthetic_state_dict(cfg: dict, seed: int = 0, as_torch: bool = True, undamped: bool = False):
-    """`undamped=True`: the two damped projections (cross_attn_image.out_proj, memory_encoder.out_proj; x0.3 above) at the
+OUTLIER_CHANNELS = (3, 41, 77)          # < 144: present in every LayerNorm of the trunk and of the memory attention
+
+
+def synthetic_state_dict(cfg: dict, seed: int = 0, as_torch: bool = True, undamped: bool = False, outlier_gain: float = 0.0):
+    """`outlier_gain=g` (tests): the LayerNorm gain of the channels OUTLIER_CHANNELS is multiplied by g in every norm1 / norm2 of the
+    Hiera trunk and norm1-3 of the memory-attention layers - a few operand channels of every QKV / fc1 / q-projection GEMM then
+    sit g x above the rest, the way trained ViT residual streams carry outlier channels (the f16-range scenario).
+    `undamped=True`: the two damped projections (cross_attn_image.out_proj, memory_encoder.out_proj; x0.3 above) at the
     gain of every other matrix - for the plug-level memory-attention / memory-encoder tests, where no recurrent loop exists
     and the damping would only make the tolerances 3x more forgiving."""
     spec = state_dict_spec(cfg)
@@ -246,6 +252,11 @@ def synthetic_state_dict(cfg: dict, seed: int = 0, as_torch: bool = True, undamp
             a = a / np.float32(DAMP_CROSS)
         if undamped and k == "memory_encoder.out_proj.weight":
             a = a / np.float32(DAMP_MEMOUT)
+        if outlier_gain and k.endswith(".weight") and len(shp) == 1 and (
+                (k.startswith("image_encoder.trunk.blocks.") and (".norm1." in k or ".norm2." in k)) or
+                (k.startswith("memory_attention.layers.") and ".norm" in k)):
+            a = a.copy()
+            a[list(OUTLIER_CHANNELS)] *= np.float32(outlier_gain)
         if as_torch:
             import torch
             a = torch.from_numpy(a)

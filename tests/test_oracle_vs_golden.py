@@ -124,3 +124,24 @@ def test_oracle_encoder_small_and_base_plus():
         for k, n in ((0, "vision_features"), (4, "backbone_fpn0"), (5, "backbone_fpn1"), (6, "backbone_fpn2")):
             ok, msg = compare(g, f"{name}/{n}", outs[k], atol=1e-4)
             assert ok, msg
+
+
+def test_outlier_channel_scenario(cfg_large):
+    """The outlier-channel golden (LayerNorm gain x 64 on three channels of every norm of the trunk and of the memory attention,
+    undamped; tests/golden/large_outliers.npz from the real reference): the oracle with the same weights.  The GPU side of this
+    scenario is tests/test_outliers_gpu.py."""
+    import os
+    import numpy as np
+    from oracle.gen_golden import OUTLIER_GAIN
+    from sam2_opt_amd.weights import synthetic_state_dict
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_outliers.npz"))
+    hi, med = g["enc/block20_norm1_absmax_outlier_vs_median"]
+    assert hi > 50 * med, (hi, med)                     # the scenario is what it claims: operand channels two orders above the rest
+    sd = synthetic_state_dict(cfg_large, seed=0, undamped=True, outlier_gain=OUTLIER_GAIN)
+    with torch.inference_mode():
+        outs = R.image_encoder(synthetic_image_normed(seed=1), sd, cfg_large)
+        o = R.memory_attention(*plug_inputs(cfg_large)["memattn_L3P12"], sd, cfg_large)
+    for k, n in ((0, "vision_features"), (4, "backbone_fpn0"), (5, "backbone_fpn1"), (6, "backbone_fpn2")):
+        scale = float(np.abs(g[f"enc/{n}/sample"]).max())
+        _check(g, "enc/" + n, outs[k], atol=5e-4 * max(scale, 1.0))
+    _check(g, "memattn_L3P12", o, atol=5e-4 * max(float(np.abs(g["memattn_L3P12/sample"]).max()), 1.0))

@@ -278,3 +278,33 @@ def test_sam_heads_match_reference_golden(sd_large, cfg_large, golden_plugs, mm)
             assert m <= 1e-4, (n, m)
     finally:
         trk.release()
+
+
+# ----------------------------------------------------------------------------- bitwise repeatability of the other plugs
+# (test_memory_attention_is_deterministic covers the memory attention; a kernel that loses or reorders a product
+# non-deterministically - the failure once seen in the RoPE epilogue - would pass every tolerance test of its plug.)
+def test_image_encoder_is_deterministic(eng):
+    from sam2_opt_amd.synthetic import synthetic_image_normed
+    img = synthetic_image_normed(seed=1).cuda()
+    outs = [[o.clone() for o in eng.image_encoder(img)] for _ in range(5)]
+    for i, o in enumerate(outs[1:]):
+        for k, (a, b) in enumerate(zip(o, outs[0])):
+            assert torch.equal(a, b), f"call {i + 1}, output {k}: {(a != b).sum().item()} elements differ"
+
+
+def test_mask_decoder_is_deterministic(eng, cfg_large):
+    from oracle.gen_golden import plug_inputs
+    inp = [t.cuda() for t in plug_inputs(cfg_large)["maskdec_N2T15"]]
+    outs = [[o.clone() for o in eng.mask_decoder(*inp)] for _ in range(5)]
+    for i, o in enumerate(outs[1:]):
+        for k, (a, b) in enumerate(zip(o, outs[0])):
+            assert torch.equal(a, b), f"call {i + 1}, output {k}: {(a != b).sum().item()} elements differ"
+
+
+def test_memory_encoder_is_deterministic(eng, cfg_large):
+    from oracle.gen_golden import plug_inputs
+    inp = [t.cuda() for t in plug_inputs(cfg_large)["memenc"]]
+    outs = [[o.clone() for o in eng.memory_encoder(*inp)] for _ in range(5)]
+    for i, o in enumerate(outs[1:]):
+        for k, (a, b) in enumerate(zip(o, outs[0])):
+            assert torch.equal(a, b), f"call {i + 1}, output {k}: {(a != b).sum().item()} elements differ"

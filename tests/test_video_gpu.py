@@ -28,8 +28,21 @@ def _sample(t, store, name):
     return a[::stride], store[name + "/sample"]
 
 
-def test_video_matches_reference_golden(predictor, cfg_large, golden_video):
+@pytest.fixture(scope="module")
+def predictor_bench_config(sd_large):
+    """encode_batch 8 + the encoder prefetch stream: the configuration bench.py times."""
+    from sam2_opt_amd.video_predictor import SAM2VideoPredictor
+    p = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=8, overlap_encode=True)
+    yield p
+    p.release()
+
+
+@pytest.mark.parametrize("which", ["batch4", "bench_config_batch8_prefetch"])
+def test_video_matches_reference_golden(request, which, cfg_large, golden_video):
+    """f16 mode against the real reference's 24-frame golden, in the test predictor's configuration (encode_batch 4, one stream) and
+    in the one bench.py times (encode_batch 8 + prefetch stream)."""
     from sam2_opt_amd.synthetic import normalize_frames, synthetic_frames_u8
+    predictor = request.getfixturevalue("predictor" if which == "batch4" else "predictor_bench_config")
     g = golden_video
     T = int(g["num_frames"][0])
     frames = normalize_frames(synthetic_frames_u8(seed=2, num_frames=T), cfg_large)
