@@ -126,22 +126,31 @@ def test_oracle_encoder_small_and_base_plus():
             assert ok, msg
 
 
-def test_outlier_channel_scenario(cfg_large):
-    """The outlier-channel golden (LayerNorm gain x 64 on three channels of every norm of the trunk and of the memory attention,
-    undamped; tests/golden/large_outliers.npz from the real reference): the oracle with the same weights.  The GPU side of this
-    scenario is tests/test_outliers_gpu.py."""
+@pytest.mark.parametrize("tag,gain_name", [("g64/", "OUTLIER_GAIN"), ("g8/", "OUTLIER_GAIN_MILD")])
+def test_outlier_channel_scenario(cfg_large, tag, gain_name):
+    """The outlier-channel goldens (LayerNorm gain x 64 / x 8 on three channels of every norm of the trunk and of the memory
+    attention, undamped; tests/golden/large_outliers.npz from the real reference): the oracle with the same weights.  The GPU side of
+    these scenarios is tests/test_outliers_gpu.py."""
     import os
     import numpy as np
-    from oracle.gen_golden import OUTLIER_GAIN
+    import oracle.gen_golden as G
     from sam2_opt_amd.weights import synthetic_state_dict
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_outliers.npz"))
-    hi, med = g["enc/block20_norm1_absmax_outlier_vs_median"]
-    assert hi > 50 * med, (hi, med)                     # the scenario is what it claims: operand channels two orders above the rest
-    sd = synthetic_state_dict(cfg_large, seed=0, undamped=True, outlier_gain=OUTLIER_GAIN)
+    hi, med = g[tag + "enc/block20_norm1_absmax_outlier_vs_median"]
+    assert hi > (50 if tag == "g64/" else 10) * med, (hi, med)       # the scenario is what it claims
+    sd = synthetic_state_dict(cfg_large, seed=0, undamped=True, outlier_gain=getattr(G, gain_name))
     with torch.inference_mode():
         outs = R.image_encoder(synthetic_image_normed(seed=1), sd, cfg_large)
         o = R.memory_attention(*plug_inputs(cfg_large)["memattn_L3P12"], sd, cfg_large)
+    # (x64 is ill-conditioned - test_outliers_gpu.py - but the oracle runs the same torch CPU kernels in the same order as the
+    # reference: measured 0.0 on both)
+    rel = 5e-4
     for k, n in ((0, "vision_features"), (4, "backbone_fpn0"), (5, "backbone_fpn1"), (6, "backbone_fpn2")):
-        scale = float(np.abs(g[f"enc/{n}/sample"]).max())
-        _check(g, "enc/" + n, outs[k], atol=5e-4 * max(scale, 1.0))
-    _check(g, "memattn_L3P12", o, atol=5e-4 * max(float(np.abs(g["memattn_L3P12/sample"]).max()), 1.0))
+        stride, size = (int(v) for v in g[f"{tag}enc/{n}/meta"])
+        got, ref = outs[k].float().numpy().reshape(-1)[::stride], g[f"{tag}enc/{n}/sample"]
+        err = float(np.abs(got - ref).max() / np.abs(ref).max())
+        print(f"oracle vs reference {tag}{n}: {err:.2e}")
+        assert err <= rel, (tag, n, err)
+    stride, size = (int(v) for v in g[tag + "memattn_L3P12/meta"])
+    got, ref = o.float().numpy().reshape(-1)[::stride], g[tag + "memattn_L3P12/sample"]
+    assert float(np.abs(got - ref).max() / np.abs(ref).max()) <= 5e-4
