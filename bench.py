@@ -106,13 +106,15 @@ def stub_main(args, rank, world):
         time.sleep(0.002 * args.frames * (1 + rank))              # the higher rank is slower: MAX over ranks must pick it
         return args.frames, torch.full((1, 1, 4, 4), float(seed))
     dt, total_frames, records, nframes, last = timed_steps(D, dist, device, one_step, args.warmup, args.steps)
+    devices = D.gather_strings(dist, f"cpu (rank {rank}, pid {os.getpid()})")
     if rank == 0:
         print(json.dumps({"metric": "frames/sec SAM2.1-hiera-large 1024x1024 video propagation", "value": round(total_frames / dt, 3),
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": args.precision, "data": "stub",
                           "config": {"workload": "orchestration test (stub predictor on CPU)", "frames_per_step": args.frames,
-                                     "parallelism": f"clips x{world} (one process per rank)", "per_rank": records, "clip_seed_rank0": seed}}), flush=True)
+                                     "parallelism": f"clips x{world} (one process per rank)", "per_rank": records, "clip_seed_rank0": seed,
+                                     "rccl_ranks": dist.get_world_size() if dist is not None else 1, "devices": devices}}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -360,6 +362,11 @@ def main():
     args = ap.parse_args()
 
     from sam2_opt_amd import dist as D
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: become one.  N fresh child processes (one per LOCAL_RANK, RANK / WORLD_SIZE / MASTER_* in
+        # their environment, the same command line), started BEFORE anything in this process touches a GPU; rank 0's JSON line
+        # passes through on the inherited stdout.
+        return D.self_spawn(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
     rank, local_rank, world = D.rank_world()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -404,6 +411,8 @@ def main():
     dt, total_frames, records, nframes, last = timed_steps(D, dist, device, one_step, args.warmup, args.steps)
     checksum = records[rank][2]
     value = total_frames / dt
+    devices = D.gather_strings(dist, f"{torch.cuda.get_device_name(device)} (cuda:{local_rank})")
+    rccl_ranks = dist.get_world_size() if dist is not None else 1
 
     roofline = None
     if not args.no_roofline and rank == 0:
@@ -426,6 +435,7 @@ def main():
             "config": {"workload": f"config3: {args.frames}-frame 1024x1024 clip per GPU, 1 click, 1 object, SAM2.1-hiera-large "
                                    "(random-init weights), propagate_in_video loop", "frames_per_step": args.frames,
                        "encode_batch": args.encode_batch, "overlap_encode_stream": not args.no_overlap, "parallelism": f"clips x{world} (one process per GPU)",
+                       "rccl_ranks": rccl_ranks, "devices": devices, "clip_seeds": [D.clip_seed_for_rank(2, r) for r in range(world)],
                        "ms_per_frame": round(dt / max(nframes, 1) * 1e3, 3), "mask_checksum": round(checksum, 6), "per_rank": records},
             "roofline": roofline, "parity": parity, "cpu_baseline": cpu_baseline, "secondary": secondary,
             "library": {"source_hash": _lib_hash()},
@@ -436,4 +446,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -59,3 +59,44 @@ def reduce_time_and_gather(dist, frames: int, seconds: float, checksum: float, d
     dist.all_gather(allr, mine)
     recs = [(int(x[0].item()), float(x[1].item()), float(x[2].item())) for x in allr]
     return float(t.item()), sum(r[0] for r in recs), recs
+
+
+def gather_strings(dist, mine: str) -> List[str]:
+    """One string per rank (device names for the result record), on every rank."""
+    if dist is None:
+        return [mine]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, mine)
+    return [str(x) for x in out]
+
+
+def self_spawn(world: int, argv: List[str]) -> int:
+    """Launcher of last resort (bench.py --gpus N started without torch.distributed.run): start `world` child processes running
+    `argv`, child r with RANK = LOCAL_RANK = r, WORLD_SIZE and a fresh MASTER_ADDR / MASTER_PORT on 127.0.0.1; wait for all of them;
+    return the largest exit code (a child that dies takes the others down instead of leaving them in a rendezvous).
+    The calling process must not have touched a GPU: the children are fresh interpreters, nothing is inherited but the environment."""
+    import socket
+    import subprocess
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(argv, env=env))
+    code = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            code = max(code, abs(rc))
+            if rc != 0:                      # one rank failed: the others would wait in a collective forever
+                for q in alive:
+                    q.terminate()
+    return code

@@ -82,11 +82,43 @@ def test_bench_orchestration_two_ranks_gloo():
     assert out["config"]["clip_seed_rank0"] == 2 and recs[0][2] == recs[1][2] == 1.0
 
 
+def test_bench_self_spawns_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: bench.py starts the two ranks itself (fresh child
+    processes, before anything touches a GPU) and the result is the same single JSON line as under torch.distributed.run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "10",
+                        "--backend", "gloo", "--stub-predictor"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and len(out["config"]["devices"]) == 2
+    assert [r_[0] for r_ in out["config"]["per_rank"]] == [20, 20]
+    pids = {d.split("pid ")[1].rstrip(")") for d in out["config"]["devices"]}
+    assert len(pids) == 2                                                   # two processes, not two threads
+
+
+def test_bench_self_spawn_propagates_a_failing_rank():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    # --backend gloo without --stub-predictor is refused by every rank: the launcher must come back non-zero, promptly
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo"], capture_output=True, text=True, timeout=120,
+                       env=env, cwd=root)
+    assert r.returncode != 0
+
+
 def test_bench_refuses_mismatched_world():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["WORLD_SIZE"] = "1"                  # a launcher's environment that disagrees with --gpus
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-predictor", "--backend", "gloo"],
                        capture_output=True, text=True, timeout=120, env=env, cwd=root)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
