@@ -50,7 +50,7 @@ def main():
     import re
     inst = {}
     for tot, k, n, f, w in rows:
-        m = re.search(r"(gemm_v2_kernel|gemm_xs_kernel|mlp_fused_kernel|gemm_ks_kernel)<[^>]*>", k)
+        m = re.search(r"(gemm_v2_kernel|gemm_xs_kernel|mlp_fused_kernel|gemm_ks_kernel|flash256_v3_kernel|hiera_attn_v2_kernel|hiera_attn_kernel|gemm_projln_kernel)<[^>]*>", k)
         if m:
             inst[m.group(0)] = {"bytes_per_launch": round(tot * 1e9 / n, -5), "launches": n}
     out["by_instantiation"] = inst
