@@ -268,7 +268,7 @@ def secondary_legs(args, pred, sd, cfg, frames, device):
     from sam2_opt_amd.route_a import PlugLevelTracker
     trk = PlugLevelTracker("large", state_dict=sd, device=device, precision=args.precision)
     try:
-        nA = min(40, frames.shape[0])
+        nA = min(100, frames.shape[0])
         fa = frames[:nA].to(device)
         for k in range(2):
             trk.start(fa, (512.0, 512.0))
@@ -287,7 +287,8 @@ def secondary_legs(args, pred, sd, cfg, frames, device):
         torch.cuda.synchronize()
         out["config1_image_encoder_batch1_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
         out["route_a_note"] = (f"plug-level route (image encoder, memory attention, prompt encoder, mask decoder, memory encoder called one by one "
-                               f"per frame with NCHW / sequence-first fp32 tensors, torch glue and memory bank): propagate loop over the first {nA} "
+                               f"per frame with NCHW / sequence-first fp32 tensors, torch glue and memory bank; the image plug looks 8 frames ahead over the clip tensor, "
+                               f"plugin.LookaheadImagePlug): propagate loop over the first {nA} "
                                f"frames, precision={args.precision}; the headline `value` is the fused route (frame features and memory bank resident "
                                "in the engine, one C call per tracked frame)")
     finally:

@@ -33,9 +33,12 @@ NO_OBJ_SCORE = -1024.0
 
 
 class PlugLevelTracker:
-    def __init__(self, model: str = "large", state_dict=None, device=None, precision: str = "f16"):
+    def __init__(self, model: str = "large", state_dict=None, device=None, precision: str = "f16", lookahead: int = 8):
+        from .plugin import LookaheadImagePlug
         self.cfg = get_config(model)
-        self.engine = Engine(self.cfg, state_dict=state_dict, max_batch=1, device=device, precision=precision)
+        self.engine = Engine(self.cfg, state_dict=state_dict, max_batch=max(1, lookahead), device=device, precision=precision)
+        # the image plug exactly as speedup_hip installs it on the reference (plugin.py): look-ahead over the clip tensor
+        self.image_plug = LookaheadImagePlug(self.engine, lookahead) if lookahead > 1 else self.engine.image_encoder
         self.device = self.engine.device
         keys = ["no_mem_embed", "no_obj_ptr", "maskmem_tpos_enc", "no_obj_embed_spatial", "obj_ptr_tpos_proj.weight", "obj_ptr_tpos_proj.bias",
                 "sam_mask_decoder.obj_score_token.weight", "sam_mask_decoder.iou_token.weight", "sam_mask_decoder.mask_tokens.weight"]
@@ -127,8 +130,11 @@ class PlugLevelTracker:
     @torch.inference_mode()
     def start(self, frames: torch.Tensor, click_xy):
         """frames: (T,3,1024,1024) normalised f32 on the device; one positive click on frame 0."""
-        self.frames, self.cond, self.non_cond = frames, OrderedDict(), OrderedDict()
-        f = self.engine.image_encoder(frames[0:1].contiguous())
+        # the reference keeps the clip as one contiguous (T,3,S,S) tensor (utils/misc.py:213-277: torch.zeros(num_frames, 3, S, S))
+        self.frames, self.cond, self.non_cond = frames.contiguous(), OrderedDict(), OrderedDict()
+        if hasattr(self.image_plug, "clear"):
+            self.image_plug.clear()
+        f = self.image_plug(self.frames[0].unsqueeze(0))       # the view the reference passes: inference_state["images"][t].unsqueeze(0)
         pix = f[6] + self.w["no_mem_embed"].view(1, -1, 1, 1)
         pts = torch.tensor([[list(click_xy)]], dtype=torch.float32, device=self.device)
         out = self._sam_heads(pix, f[4], f[5], pts, torch.ones(1, 1, dtype=torch.int32, device=self.device), True)
@@ -145,7 +151,7 @@ class PlugLevelTracker:
             if t in self.cond:
                 yield t, self.cond[t]["pred_masks"]
                 continue
-            f = self.engine.image_encoder(self.frames[t:t + 1].contiguous())
+            f = self.image_plug(self.frames[t].unsqueeze(0))
             pix = self._memory_conditioned(t, f, T)
             out = self._sam_heads(pix, f[4], f[5], None, None, True)
             self._encode_memory(f[6], out, False)

@@ -163,3 +163,32 @@ def test_model_size_detection():
         del sd[k]
     with pytest.raises(RuntimeError, match="not a SAM 2.1"):
         _detect_model(sd)
+
+
+def test_reference_video_loop_reaches_the_plug_with_clip_views_and_gets_lookahead(ref_predictor):
+    """The reference's own `_get_image_feature` (sam2_video_predictor_official.py:810-841) on a device-resident clip tensor: the
+    frame it hands to `inference_image` is a view of the clip, so the look-ahead plug encodes 8 frames per engine call, and a clip
+    kept on another device (copied per frame, like `offload_video_to_cpu`) falls back to one frame per call."""
+    from sam2_opt_amd.plugin import release_hip, speedup_hip
+    model = ref_predictor
+    eng = StubEngine()
+    eng.max_batch = 8
+    speedup_hip(model, plugs=("image",), engine=eng, lookahead=8)
+    try:
+        T = 11
+        state = {"images": torch.zeros(T, 3, 1024, 1024), "device": torch.device("cpu"), "cached_features": {}}
+        with torch.inference_mode():
+            for t in range(T):
+                feats = model._get_image_feature(state, t, 1)
+                assert feats[0].shape == (1, 3, 1024, 1024)
+        enc = [c[1][0] for c in eng.calls if c[0] == "image_encoder"]
+        assert enc == [8, 3], enc
+        # a half-precision clip: `.float()` makes a per-frame copy -> no view, one frame per call
+        eng.calls.clear()
+        state = {"images": torch.zeros(3, 3, 1024, 1024, dtype=torch.float16), "device": torch.device("cpu"), "cached_features": {}}
+        with torch.inference_mode():
+            for t in range(3):
+                model._get_image_feature(state, t, 1)
+        assert [c[1][0] for c in eng.calls if c[0] == "image_encoder"] == [1, 1, 1]
+    finally:
+        release_hip(model)

@@ -10,7 +10,7 @@ from sam2_opt_amd.weights import synthetic_state_dict
 
 cfg = get_config("large")
 sd = synthetic_state_dict(cfg, seed=0)
-trk = PlugLevelTracker("large", state_dict=sd)
+trk = PlugLevelTracker("large", state_dict=sd, precision=os.environ.get("PRECISION", "f16s"), lookahead=int(os.environ.get("LOOKAHEAD", "8")))
 frames = normalize_frames(synthetic_frames_u8(seed=2, num_frames=40), cfg).cuda()
 acc = collections.defaultdict(list)
 
@@ -31,7 +31,7 @@ def wrap(name):
 for n in ("image_encoder", "memory_attention", "prompt_encoder_full", "mask_decoder", "memory_encoder"):
     wrap(n)
 trk.start(frames, (512.0, 512.0))
-for rep in range(2):
+for rep in range(3):
     acc.clear()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -41,7 +41,9 @@ for rep in range(2):
     tot = 0.0
     print(f"pass {rep}: {n} frames, {wall * 1e3 / n:.2f} ms per frame ({n / wall:.1f} fps)")
     for k, evs in acc.items():
-        ms = [a.elapsed_time(b) for a, b in evs[10:]]
+        ms = [a.elapsed_time(b) for a, b in (evs[10:] if len(evs) > 12 else evs)]
         tot += sum(ms) / len(ms)
         print(f"    {k:22s} {sum(ms) / len(ms):7.3f} ms per call ({len(evs)} calls)")
     print(f"    plugs together {tot:.3f} ms; the rest is torch glue, layout transposes and launch gaps")
+    if hasattr(trk.image_plug, "stats"):
+        print("    look-ahead plug:", trk.image_plug.stats)
