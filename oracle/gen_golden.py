@@ -2,7 +2,7 @@
 from /root/reference on seeded synthetic inputs and weights.  Container-only; the
 outputs (data, not code) are committed and travel to the GPU box.
 
-    python -m oracle.gen_golden [plugs] [video] [tiny] [interact] [reverse] [multi] [box] [long] [opts] [ingest] [sizes] [outliers]
+    python -m oracle.gen_golden [plugs] [video] [tiny] [interact] [reverse] [multi] [box] [long] [opts] [ingest] [sizes] [outliers] [video2]
 
 Weights: sam2_opt_amd.weights.synthetic_state_dict(cfg, seed=0)   (regenerated anywhere)
 Inputs : sam2_opt_amd.synthetic.*  with the seeds named below.
@@ -191,6 +191,32 @@ def gen_video():
     full["num_frames"] = np.array([n], dtype=np.int64)
     np.savez_compressed(os.path.join(GOLD, "large_video24_full.npz"), **full)
     print("video done", time.time() - t0)
+
+
+@torch.inference_mode()
+def gen_video2():
+    """A second propagation golden, independent of the one the f16s plan was tuned on: clip seed 7, click at (300, 640), WEIGHT seed 1,
+    16 frames - every pixel of the low-res logits of every frame (tests/golden/large_video16_w1_full.npz)."""
+    cfg = get_config("large")
+    sd = synthetic_state_dict(cfg, seed=1)
+    model = build_reference_model(cfg, "video", sd, fill_hole_area=0)
+    frames = normalize_frames(synthetic_frames_u8(seed=7, num_frames=16), cfg)
+    import sam2.sam2_video_predictor_official as vp
+    vp.load_video_frames = lambda **kw: (frames, 1024, 1024)
+    full = {}
+    t0 = time.time()
+    state = model.init_state(video_path="synthetic")
+    model.add_new_points_or_box(state, frame_idx=0, obj_id=1, points=np.array([(300.0, 640.0)], np.float32), labels=np.array([1], np.int32))
+    n = 0
+    for fi, ids, vm in model.propagate_in_video(state):
+        out = state["output_dict_per_obj"][0]
+        cur = out["cond_frame_outputs"].get(fi) or out["non_cond_frame_outputs"][fi]
+        full[f"f{fi}/pred_masks"] = cur["pred_masks"].float().cpu().numpy()
+        print("frame", fi, time.time() - t0, float((cur["pred_masks"] > 0).float().mean()), flush=True)
+        n += 1
+    full["num_frames"] = np.array([n], dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "large_video16_w1_full.npz"), **full)
+    print("video2 done", time.time() - t0)
 
 
 INTERACT_FRAMES = 6
@@ -519,3 +545,5 @@ if __name__ == "__main__":
         gen_sizes()
     if "outliers" in which:
         gen_outliers()
+    if "video2" in which:
+        gen_video2()

@@ -240,3 +240,37 @@ def test_video_precise_matches_reference_golden_all_pixels(sd_large, cfg_large, 
         assert worst_low <= guard, worst_low
     finally:
         pred.release()
+
+
+@pytest.mark.parametrize("precision,tol", [("f16s", 1e-3), ("f16x3", 1e-4), ("f16", 4e-3)])
+def test_second_clip_other_weights_matches_reference_golden(cfg_large, precision, tol):
+    """The f16s plan was measured on ONE clip with ONE set of synthetic weights (the golden above).  This golden is independent of
+    it - weight seed 1, clip seed 7, click at (300, 640), 16 frames, every low-res pixel from the real reference
+    (oracle/gen_golden.py video2) - and holds the modes to the same bars: f16s / f16x3 inside the north-star 1e-3 on all three
+    metrics, f16 inside its bf16-class tier."""
+    from sam2_opt_amd.synthetic import normalize_frames, synthetic_frames_u8
+    from sam2_opt_amd.video_predictor import SAM2VideoPredictor
+    from sam2_opt_amd.weights import synthetic_state_dict
+    g = np.load(os.path.join(ROOT, "tests", "golden", "large_video16_w1_full.npz"))
+    T = int(g["num_frames"][0])
+    sd = synthetic_state_dict(cfg_large, seed=1)
+    frames = normalize_frames(synthetic_frames_u8(seed=7, num_frames=T), cfg_large)
+    pred = SAM2VideoPredictor("large", state_dict=sd, encode_batch=8, precision=precision, overlap_encode=True)
+    try:
+        st = pred.init_state(frames=frames, video_height=1024, video_width=1024)
+        pred.add_new_points_or_box(st, 0, 1, points=np.array([[300.0, 640.0]], np.float32), labels=np.array([1], np.int32))
+        worst = [0.0, 0.0, 0.0]
+        n = 0
+        for t, ids, vm in pred.propagate_in_video(st):
+            od = st["output_dict_per_obj"][0]
+            cur = od["cond_frame_outputs"].get(t) or od["non_cond_frame_outputs"][t]
+            got, ref = cur["pred_masks"].float().cpu().numpy(), g[f"f{t}/pred_masks"]
+            d = got - ref
+            worst = [max(worst[0], float(np.abs(d).max() / np.abs(ref).max())), max(worst[1], float(np.linalg.norm(d) / np.linalg.norm(ref))),
+                     max(worst[2], float(((got > 0) != (ref > 0)).mean()))]
+            n += 1
+        assert n == T
+        print(f"[parity] {precision} second clip (weights seed 1), {T} frames, all pixels: max_rel={worst[0]:.3e} l2={worst[1]:.3e} dis={worst[2]:.3e}", flush=True)
+        assert max(worst) <= tol, worst
+    finally:
+        pred.release()
