@@ -617,7 +617,7 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
       return sam2mi_set_error(ctx, "sam2mi_finalize_weights", "head_dim must be 56, 72 or 96 (hiera tiny / small / base+ / large)");
     for (int i = 0; i < 4; ++i)
       if (c.window_spec[i] < 2 || c.window_spec[i] > 16) return sam2mi_set_error(ctx, "sam2mi_finalize_weights", "window sizes 2..16 are supported");
-    if (ctx->precise) return sam2mi_set_error(ctx, "sam2mi_finalize_weights", "the f16x3 mode is implemented for hiera-large only");
+    if (ctx->precise) return sam2mi_set_error(ctx, "sam2mi_finalize_weights", "the split-operand precision modes (f16x3, f16s) are implemented for hiera-large only");
   }
 
   // ---- Hiera block table (hieradet.py:243-268)

@@ -15,19 +15,19 @@ import torch
 import torch.nn.functional as F
 
 from .config import get_config
-from .native import Engine
+from .native import Engine, default_precision
 
 
 class SAM2ImagePredictor:
     def __init__(self, model: str = "large", state_dict=None, ckpt_path: Optional[str] = None, device=None,
-                 mask_threshold: float = 0.0, max_batch: int = 8, precision: str = "f16"):
+                 mask_threshold: float = 0.0, max_batch: int = 8, precision: Optional[str] = None):
         self.cfg = get_config(model)
         if state_dict is None and ckpt_path is not None:
             state_dict = torch.load(ckpt_path, map_location="cpu", weights_only=True)["model"]
         if state_dict is None:
             raise ValueError("state_dict or ckpt_path is required")
         self.max_batch = max_batch
-        self.engine = Engine(self.cfg, state_dict=state_dict, max_batch=max_batch, feat_slots=max(2 * max_batch, 16), device=device, precision=precision)
+        self.engine = Engine(self.cfg, state_dict=state_dict, max_batch=max_batch, feat_slots=max(2 * max_batch, 16), device=device, precision=precision or default_precision(model))
         self.device = self.engine.device
         self.mask_threshold = mask_threshold
         self.image_size = self.cfg["image_size"]

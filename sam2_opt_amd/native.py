@@ -34,6 +34,13 @@ ABI_VERSION = 2
 PRECISIONS = {"f16": 0, "f16x3": 1, "f16s": 2}      # SAM2MI_PRECISION_* (include/sam2mi.h)
 
 
+def default_precision(model) -> str:
+    """What the predictors use when no precision is given: the fastest mode inside the north-star bar (masks within 1e-3 of the
+    reference's fp32 path) where it exists - "f16s" for hiera-large; the padded-window sizes only have "f16"."""
+    name = model if isinstance(model, str) else model.get("name", "")
+    return "f16s" if name in ("large", "sam2.1_hiera_large") else "f16"
+
+
 class MemSelect(C.Structure):
     _fields_ = [("num_mem", C.c_int), ("mem_slot", C.c_int * 16), ("mem_tpos", C.c_int * 16), ("num_ptr", C.c_int),
                 ("ptr_slot", C.c_int * 32), ("ptr_dt", C.c_float * 32), ("ptr_tmax", C.c_float)]
@@ -93,8 +100,10 @@ class Engine:
 
     def __init__(self, model: str = "large", state_dict=None, max_batch: int = 1, bank_slots: int = 64,
                  feat_slots: int = 16, device: Optional[torch.device] = None, precision: str = "f16"):
-        """`precision`: "f16" (default: f16 MFMA operands, f32 accumulation) or "f16x3" (every MFMA operand as a 2-term f16
-        split, three MFMAs per product: the "masks within 1e-3 of the reference" class at 2-3x the MFMA work)."""
+        """`precision` (include/sam2mi.h): "f16" (plain f16 MFMA operands, f32 accumulation: the bf16-class tier, ~2e-3 of the
+        reference's fp32 path), "f16s" (selective 2-term f16 split of the operands whose rounding carries the error: masks within 1e-3 at
+        0.80x the f16 rate; what bench.py and plugin.speedup_hip use by default), "f16x3" (every operand split, three MFMAs per product:
+        ~1e-5 at 0.38x).  The split modes exist for hiera-large only."""
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         self.precision = precision

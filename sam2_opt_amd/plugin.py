@@ -178,6 +178,10 @@ def _engine_for(model, precision: str = "f16", engine=None, max_batch: int = 1) 
             dev = next(model.parameters()).device
             if dev.type != "cuda":
                 raise RuntimeError("speedup('hip') needs the model on a ROCm GPU (model.to('cuda'))")
+            if size != "large" and precision != "f16":
+                import warnings
+                warnings.warn(f"speedup('hip'): the split-operand precision modes exist for hiera-large only; hiera-{size} runs in 'f16'")
+                precision = "f16"
             eng = Engine(size, state_dict=sd, max_batch=max_batch, device=dev, precision=precision)
         model._sam2mi_engine = eng
     return eng

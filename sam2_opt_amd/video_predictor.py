@@ -30,7 +30,7 @@ import torch
 
 from .config import get_config
 from .memory_select import select_memory
-from .native import Engine, MemSelect
+from .native import Engine, MemSelect, default_precision
 from .synthetic import normalize_frames
 
 
@@ -50,7 +50,7 @@ _PREFETCH_EARLY = os.environ.get("SAM2MI_PREFETCH_EARLY") is not None
 class SAM2VideoPredictor:
     def __init__(self, model: str = "large", state_dict=None, ckpt_path: Optional[str] = None, device=None,
                  encode_batch: int = 8, bank_slots: int = 384, fill_hole_area: int = 0, non_overlap_masks: bool = False,
-                 overlap_encode: bool = True, precision: str = "f16", clear_non_cond_mem_around_input: bool = False,
+                 overlap_encode: bool = True, precision: Optional[str] = None, clear_non_cond_mem_around_input: bool = False,
                  add_all_frames_to_correct_as_cond: bool = False, max_cond_frames_in_attn: int = -1,
                  memory_temporal_stride_for_eval: int = 1, prefetch_depth: int = 1):
         self.cfg = get_config(model)
@@ -62,7 +62,7 @@ class SAM2VideoPredictor:
         self.encode_batch = int(encode_batch)
         self.prefetch_depth = max(1, int(prefetch_depth))         # batches the encoder stream may be ahead of the tracking (feature cache = depth + 1 batches)
         self.engine = Engine(self.cfg, state_dict=state_dict, max_batch=self.encode_batch, bank_slots=bank_slots,
-                             feat_slots=max((1 + self.prefetch_depth) * self.encode_batch, 4), device=device, precision=precision)
+                             feat_slots=max((1 + self.prefetch_depth) * self.encode_batch, 4), device=device, precision=precision or default_precision(model))
         self.device = self.engine.device
         self.image_size = self.cfg["image_size"]
         self.num_maskmem = self.cfg["num_maskmem"]

@@ -16,7 +16,7 @@ CLICK = (512.0, 512.0)
 @pytest.fixture(scope="module")
 def predictor(sd_large):
     from sam2_opt_amd.video_predictor import SAM2VideoPredictor
-    p = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4)
+    p = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4, precision="f16")      # this file holds the f16 mode to its tier
     yield p
     p.release()
 
@@ -32,7 +32,7 @@ def _sample(t, store, name):
 def predictor_bench_config(sd_large):
     """encode_batch 8 + the encoder prefetch stream: the configuration bench.py times."""
     from sam2_opt_amd.video_predictor import SAM2VideoPredictor
-    p = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=8, overlap_encode=True)
+    p = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=8, overlap_encode=True, precision="f16")
     yield p
     p.release()
 
