@@ -60,6 +60,8 @@ struct Flash256Params {
                                 //   combines the partials itself (gemm_rowln.hip)
   float scale_log2e;            // unused by the kernel (q is pre-scaled); kept for the debug entry point
   size_t out_lo_off;            // split-f16 mode: `out` is written as hi + lo (common.h); 0: off
+  int dv;                       // channels of the values: 0 / 256, or 64: vT is [64, ldvT] (the memory tokens themselves, value projection
+                                //   applied by the consumer), o_part [splits, Nq, 64]; partials only (out must be null)
 };
 hipError_t flash256_launch(const Flash256Params& p, hipStream_t stream);
 hipError_t flash256_init();   // dynamic-LDS attribute, once

@@ -191,8 +191,16 @@ static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt
 // ABL != 0: timing ablations for tuning (results are wrong): 1 no LDS-DMA in the loop, 2 no barrier / vmcnt wait,
 // 3 no exponentials, 4 no P.V product, 5 no next-tile QK product
 // MASK: Nk is not a multiple of 32 (keys past Nk in the last tile are masked when the score chains are summed)
-template <int ABL, bool MASK, int NST>
+// DV: channels of the VALUES (256, or 64 = the cross-attention of the memory attention with the value projection moved BEHIND the
+// attention: softmax(q k^T) (m Wv^T + bv) = (softmax(q k^T) m) Wv^T + bv, so the kernel multiplies the probabilities with the 64-channel
+// memory tokens themselves - a quarter of the P.V products, of the V^T tile bytes in LDS and of the O accumulators - and the consumer
+// (gemm_rowln.hip, KC = 64) applies Wo Wv and Wo bv + bo composed at weight-load time.  Scores keep their 256 channels.)
+template <int ABL, bool MASK, int NST, int DV = 256>
 __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Params p) {
+  constexpr int STAGE_BYTES = K3_TILE_B + DV * 64;     // K image + V^T image [DV][32 keys]
+  constexpr int VPW = DV / 64;                         // V^T pieces (16 d rows x 64 B) per wave and tile: 4 or 1
+  constexpr int PPT = 4 + VPW;                         // LDS-DMA pieces per wave and tile
+  constexpr int OT = DV / 32;                          // O^T row tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -216,27 +224,30 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
 #pragma unroll
     for (int s = 0; s < 16; ++s) qf[s] = *reinterpret_cast<const half8*>(qp + s * 16);
   }
-  int k_src[4], v_src[4];          // element offsets (fit 32 bits)
+  int k_src[4], v_src[VPW];        // element offsets (fit 32 bits)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int kp = wave * 4 + j;                       // K piece 0..15: 2 key rows x 32 chunks
     const int krow = kp * 2 + (lane >> 5), kpc = lane & 31;
     k_src[j] = krow * p.ldk + ((kpc ^ (krow & 1)) << 3);
-    const int vp = wave * 4 + j;                       // V^T piece 0..15: 16 d rows x 4 chunks
+  }
+#pragma unroll
+  for (int j = 0; j < VPW; ++j) {
+    const int vp = wave * VPW + j;                     // V^T piece 0..DV/16-1: 16 d rows x 4 chunks
     const int vrow = vp * 16 + (lane >> 2), vpc = lane & 3;
     v_src[j] = vrow * p.ldvT + ((vpc ^ ((vrow >> 2) & 3)) << 3);
   }
   // tile t_lo + min(i, n-1) -> ring stage i % NST.  Past the last tile the last one is simply loaded again (into a free
   // stage, never read): every iteration then issues exactly 8 pieces per wave and the loop needs no branch around the DMA.
   auto issue = [&](int i) {
-    char* sb = smem + (i % NST) * STAGE3_B;
+    char* sb = smem + (i % NST) * STAGE_BYTES;
     const int tile = t_lo + min(i, n - 1);
     const half_t* kb = p.k + (size_t)tile * 32 * p.ldk;
     const half_t* vb = p.vT + tile * 32;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(kb + k_src[j]), (lds_ptr_t)(sb + (wave * 4 + j) * K3_PIECE), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vb + v_src[j]), (lds_ptr_t)(sb + K3_TILE_B + (wave * 4 + j) * 1024), 16, 0, 0);
+      if (j < VPW) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(vb + v_src[j]), (lds_ptr_t)(sb + K3_TILE_B + (wave * VPW + j) * 1024), 16, 0, 0);
     }
   };
   // K fragments of ring tile i (rows permuted by pi), 8 k-steps at a time.  Every batch of LDS reads is pinned in
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
   const int krow_off = (krow >> 1) * K3_PIECE + (krow & 1) * 512 + ((fh ^ (krow & 1)) << 4);
   struct F8 { half8 f[8]; };
   auto read_k8 = [&](int i, int half) {
-    const char* sK = smem + (i % NST) * STAGE3_B + krow_off;
+    const char* sK = smem + (i % NST) * STAGE_BYTES + krow_off;
     F8 k;
 #pragma unroll
     for (int j = 0; j < 8; ++j) k.f[j] = *reinterpret_cast<const half8*>(sK + (8 * half + j) * 32);
@@ -254,11 +265,11 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
   };
   // V^T fragments of ring tile i: row d = 32 t + fr, keys 16 ks + 8 fh .. + 7 = 16-B chunk 2 ks + fh; t = 4 half .. + 3
   const int vsw = (fr >> 2) & 3;                       // ((32 t + fr) >> 2) & 3
-  auto read_v8 = [&](int i, int half) {
-    const char* sV = smem + (i % NST) * STAGE3_B + K3_TILE_B + fr * 64 + half * 8192;
+  auto read_v8 = [&](int i, int half) {                  // DV = 64: one half with 2 row tiles (f[0..3])
+    const char* sV = smem + (i % NST) * STAGE_BYTES + K3_TILE_B + fr * 64 + half * 8192;
     F8 v;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < (OT < 4 ? OT : 4); ++t) {
       v.f[2 * t] = *reinterpret_cast<const half8*>(sV + t * 2048 + (((0 + fh) ^ vsw) << 4));
       v.f[2 * t + 1] = *reinterpret_cast<const half8*>(sV + t * 2048 + (((2 + fh) ^ vsw) << 4));
     }
@@ -281,9 +292,9 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
     for (int j = 0; j < 8; ++j) sa = mfma32(k.f[j], qf[8 * half + j], sa);
   };
 
-  f32x16 o[8];
+  f32x16 o[OT];
 #pragma unroll
-  for (int t = 0; t < 8; ++t)
+  for (int t = 0; t < OT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
   // Deferred rescale: probabilities are taken against a per-query REFERENCE maximum m_ref that is only raised when
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
   if (n > 0) {
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t) issue(t);
-    wait_vm<8 * (NST - 2)>();
+    wait_vm<PPT * (NST - 2)>();
     __builtin_amdgcn_s_barrier();
     f32x16 s;
     {
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
         const float alpha = __builtin_amdgcn_exp2f(m_ref - m_new);
         l_run *= alpha;
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < OT; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
         m_ref = m_new;
@@ -334,14 +345,15 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
         // here: s / tmax belong to tile i and tmax <= m_ref + RESCALE_THR on every lane
         // tile i+1 landed (with 4 stages tile i+2 may stay in flight); every wave is past tile i-1 -> stage (i-1) % NST is free
         if (ABL != 2) {
-          wait_vm<8 * (NST - 3)>();
+          wait_vm<PPT * (NST - 3)>();
           __builtin_amdgcn_s_barrier();
         }
         // next tile's scores (garbage past the last tile: never used) run beside this tile's exponentials
         const F8 ka = read_k8(i + 1, 0);
         const F8 kb = read_k8(i + 1, 1);
         const F8 va = read_v8(i, 0);
-        const F8 vb = read_v8(i, 1);
+        F8 vb;
+        if constexpr (OT > 4) vb = read_v8(i, 1);
         __builtin_amdgcn_sched_barrier(0);
         // LDS-DMA pieces are expensive to issue (60+ cycles each): they go out one per pair of MFMAs instead of as a
         // burst behind the barrier, where the MFMA pipe would sit idle under them
@@ -375,18 +387,22 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
         // ---- O^T += V^T P^T, beside the mask / row maximum of the next tile's scores
         if (ABL != 4) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
+          for (int t = 0; t < (OT < 4 ? OT : 4); ++t) {
             o[t] = mfma32(va.f[2 * t], pf[0], o[t]);
             o[t] = mfma32(va.f[2 * t + 1], pf[1], o[t]);
           }
+          if constexpr (OT > 4) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            o[4 + t] = mfma32(vb.f[2 * t], pf[0], o[4 + t]);
-            o[4 + t] = mfma32(vb.f[2 * t + 1], pf[1], o[4 + t]);
+            for (int t = 0; t < 4; ++t) {
+              o[4 + t] = mfma32(vb.f[2 * t], pf[0], o[4 + t]);
+              o[4 + t] = mfma32(vb.f[2 * t + 1], pf[1], o[4 + t]);
+            }
           }
         } else {
+          if constexpr (OT > 4) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(va.f[j]), "v"(vb.f[j]));
+            for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(va.f[j]), "v"(vb.f[j]));
+          }
           asm volatile("" ::"v"(pf[0]), "v"(pf[1]));
         }
         s = qk_mask(sa, p.Nk - (t_lo + i + 1) * 32);
@@ -403,9 +419,9 @@ __global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Param
 
   // ---- partial results
   const int q = q0 + fr;
-  float* op = p.o_part + ((size_t)split * p.Nq + q) * D;
+  float* op = p.o_part + ((size_t)split * p.Nq + q) * DV;
 #pragma unroll
-  for (int t = 0; t < 8; ++t)
+  for (int t = 0; t < OT; ++t)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 v = {o[t][4 * g], o[t][4 * g + 1], o[t][4 * g + 2], o[t][4 * g + 3]};
@@ -673,15 +689,22 @@ hipError_t flash256_init() {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, NST_MAX * STAGE3_B);
     if (e != hipSuccess) return e;
   }
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&flash256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B);
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flash256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B);
+    if (e != hipSuccess) return e;
+  }
 #else
   const void* v3[2] = {reinterpret_cast<const void*>(&flash256_v3_kernel<0, false, 4>), reinterpret_cast<const void*>(&flash256_v3_kernel<0, true, 4>)};
   for (int i = 0; i < 2; ++i) {
     hipError_t e = hipFuncSetAttribute(v3[i], hipFuncAttributeMaxDynamicSharedMemorySize, NST_MAX * STAGE3_B);
     if (e != hipSuccess) return e;
   }
-  return hipSuccess;
 #endif
+  for (const void* f : {reinterpret_cast<const void*>(&flash256_v3_kernel<0, false, 4, 64>), reinterpret_cast<const void*>(&flash256_v3_kernel<0, true, 4, 64>)}) {
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, NST_MAX * (K3_TILE_B + 64 * 64));
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 // v3 runs one 128-query workgroup per CU: pick the KV split count that makes the grid one full wave of 256 workgroups
@@ -714,6 +737,14 @@ int flash256_pick_splits(int Nq, int Nk) {
 hipError_t flash256_launch(const Flash256Params& p, hipStream_t stream) {
   if (p.Nq % 128 || p.Nk <= 0 || p.splits <= 0 || (p.ldq & 7) || (p.ldk & 7) || (p.ldvT & 7) || (p.ldout & 3)) return hipErrorInvalidValue;
   const dim3 grid((p.Nq / 128) * p.splits), block(256);
+  if (p.dv == 64) {                 // values in the 64-channel memory space (cross-attention of the memory attention); partials only
+    if (p.out) return hipErrorInvalidValue;
+    const size_t lds = (size_t)4 * (K3_TILE_B + 64 * 64);
+    if (p.Nk % 32) flash256_v3_kernel<0, true, 4, 64><<<grid, block, lds, stream>>>(p);
+    else flash256_v3_kernel<0, false, 4, 64><<<grid, block, lds, stream>>>(p);
+    return hipGetLastError();
+  }
+  if (p.dv != 0 && p.dv != 256) return hipErrorInvalidValue;
 #ifdef SAM2MI_EXPERIMENTAL
   static const bool use_v2 = getenv("SAM2MI_FLASH_V2") != nullptr;      // A/B switch: the 2-waves-per-SIMD kernel
   static const int abl = getenv("SAM2MI_FLASH_ABL") ? atoi(getenv("SAM2MI_FLASH_ABL")) : 0;     // tuning only (wrong results)

@@ -223,6 +223,22 @@ __global__ void pool_tokens_split_kernel(const half_t* __restrict__ in, size_t i
   out[ot * ldout + c + out_lo] = ml;
 }
 
+// [R, 64] f16 row-major -> [64, ld] (column r = input row r): 64 x 64 tiles through LDS.  The memory tokens as the V^T operand of the
+// d = 256 flash kernel (DV = 64, attn_flash256.hip)
+__global__ __launch_bounds__(256) void transpose_rows64_f16_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int R, int ld) {
+  __shared__ half_t t[64][66];
+  const int r0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    t[r][c] = (r0 + r < R) ? in[(size_t)(r0 + r) * 64 + c] : (half_t)0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < ld) out[(size_t)c * ld + r0 + r] = t[r][c];
+  }
+}
+
 // ------------------------------------------------------------------ token re-ordering between window sizes
 // 4 channels per thread (C % 4 == 0); frame b of the output goes to dst.p[b] (the feature-cache slots of the frames are not
 // contiguous), or to out + b * H * W * C when dst.p[0] is null.
@@ -350,6 +366,11 @@ hipError_t pool_tokens_f16_launch(const half_t* in, int ldin, half_t* out, int l
 }
 hipError_t pool_tokens_split_launch(const half_t* in, size_t in_lo, int ldin, half_t* out, size_t out_lo, int ldout, int nwin, int w, int C, hipStream_t s) {
   pool_tokens_split_kernel<<<grid1d((size_t)nwin * (w / 2) * (w / 2) * C), dim3(256), 0, s>>>(in, in_lo, ldin, out, out_lo, ldout, nwin, w, C);
+  return hipGetLastError();
+}
+hipError_t transpose_rows64_f16_launch(const half_t* in, half_t* out, int R, int ld, hipStream_t s) {
+  if (R <= 0 || ld < R) return hipErrorInvalidValue;
+  transpose_rows64_f16_kernel<<<dim3((ld + 63) / 64), dim3(256), 0, s>>>(in, out, R, ld);
   return hipGetLastError();
 }
 hipError_t permute_tokens_launch(const float* in, float* out, int B, int H, int W, int C, int w_in, int w_out,

@@ -59,6 +59,8 @@ struct MemAttnLayerW {
   Norm n1, n2, n3;
   Lin16 self_qkv;   // [768, 256] = q_proj | k_proj | v_proj
   Lin16 self_out, cross_q, cross_out, lin1, lin2;
+  Lin16 cross_vo;   // [256, 64] = out_proj . v_proj of the cross-attention (bias: Wo bv + bo), composed in f64 at weight-load time: the
+                    // value projection applied BEHIND the attention (attn_flash256.hip DV = 64, gemm_rowln.hip KC = 64)
 };
 
 struct AttnW32 { Lin32 q, k, v, o; };          // token-side projections (fp32)
@@ -152,6 +154,8 @@ struct sam2mi_ctx {
   // ---- memory attention
   std::vector<MemAttnLayerW> mal;
   Lin16 cross_k_all, cross_v_all;    // [4*256, 64]
+  half_t* t_vinT16 = nullptr;        // [TRACK_MAX_N][64, t_nk_cap] memory tokens transposed (V^T operand of the cross-attention, DV = 64)
+  bool use_mem_space_values = true;  // the cross-attention multiplies the probabilities with the memory tokens, Wo Wv behind it (fused tail only)
   Norm ma_norm;
   float* rope_cos = nullptr;         // [4096, 128]
   float* rope_sin = nullptr;

@@ -218,8 +218,9 @@ int run_rowln(sam2mi_ctx* ctx, hipStream_t s, const RowLnParams& p) {
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_gemm, s, e0, e1);
   CHK(gemm_rowln_launch(p, s));
   // algorithmic bytes: partials (or the f16 operand) + weights + residual in and out + f16 LayerNorm output
-  const double bytes = (p.o_part ? (double)p.splits * p.M * (256.0 * 4 + 8) : p.M * 512.0) + 256.0 * 512 + p.M * 256.0 * (4 + 4 + 2);
-  if (ctx->prof_on) prof_end_named(ctx, ctx->prof_gemm, "gemm_rowln_kernel", s, e0, e1, 2.0 * p.M * 256.0 * 256.0, bytes);
+  const double kc = p.kc == 64 ? 64.0 : 256.0;
+  const double bytes = (p.o_part ? (double)p.splits * p.M * (kc * 4 + 8) : p.M * kc * 2.0) + 256.0 * kc * 2 + p.M * 256.0 * (4 + 4 + 2);
+  if (ctx->prof_on) prof_end_named(ctx, ctx->prof_gemm, p.kc == 64 ? "gemm_rowln_kernel<64>" : "gemm_rowln_kernel<256>", s, e0, e1, 2.0 * p.M * 256.0 * kc, bytes);
   return 0;
 }
 
@@ -241,8 +242,13 @@ int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p) {
   if (ctx->prof_on) prof_begin(ctx, ctx->prof_attn, s, e0, e1);
   CHK(flash256_launch(p, s));
   // algorithmic bytes: q, K, V^T in (f16), the un-normalised f32 partial outputs + their (max, sum) pairs out (one set per KV split)
-  if (ctx->prof_on) prof_end_named(ctx, ctx->prof_attn, (p.Nk % 32) ? "flash256_v3_kernel<0, true, 4>" : "flash256_v3_kernel<0, false, 4>", s, e0, e1,
-                                   4.0 * p.Nq * (double)p.Nk * 256.0, 512.0 * (p.Nq + 2.0 * p.Nk) + (double)p.splits * p.Nq * (256.0 * 4 + 8));
+  if (ctx->prof_on) {
+    const double dv = p.dv == 64 ? 64.0 : 256.0;
+    const char* nm = p.dv == 64 ? ((p.Nk % 32) ? "flash256_v3_kernel<0, true, 4, 64>" : "flash256_v3_kernel<0, false, 4, 64>")
+                                : ((p.Nk % 32) ? "flash256_v3_kernel<0, true, 4, 256>" : "flash256_v3_kernel<0, false, 4, 256>");
+    prof_end_named(ctx, ctx->prof_attn, nm, s, e0, e1, 2.0 * p.Nq * (double)p.Nk * (256.0 + dv),
+                   512.0 * p.Nq + 2.0 * p.Nk * (256.0 + dv) + (double)p.splits * p.Nq * (dv * 4 + 8));
+  }
   return 0;
 }
 
@@ -487,6 +493,7 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   ctx->use_xs = (!ctx->precise || ctx->selective) && getenv("SAM2MI_NO_XS") == nullptr;      // f16s: the linears planned as plain f16
   ctx->use_rowln = (!ctx->precise || (ctx->selective && ctx->plan_grp[GRP_MA] == PREC_F16)) && getenv("SAM2MI_NO_ROWLN") == nullptr;
   ctx->use_projln = !ctx->precise && getenv("SAM2MI_NO_PROJLN") == nullptr;
+  ctx->use_mem_space_values = getenv("SAM2MI_NO_MEM_SPACE_VALUES") == nullptr;      // A/B switch (needs the fused tail)
   // norm1 inside the operand load of the X-stationary QKV kernel: pays in stage 1 only (C = 144: the QKV launch goes 162 -> 200 us and the
   // 107-us LayerNorm launch disappears; same box, 8-frame pass 28.14 -> 27.89 ms with 144, 27.98 with 288, worse with 576)
   ctx->ln1_fuse_maxc = ctx->precise ? 0 : (getenv("SAM2MI_LN1_FUSE_MAXC") ? atoi(getenv("SAM2MI_LN1_FUSE_MAXC")) : 144);
@@ -822,6 +829,24 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
       m.cross_out = pk.lin16(p + "cross_attn_image.out_proj");
       m.lin1 = pk.lin16(p + "linear1");
       m.lin2 = pk.lin16(p + "linear2");
+      {                          // Wo Wv [256, 64] and Wo bv + bo: softmax(q k^T) (m Wv^T + bv) Wo^T + bo = (softmax(q k^T) m) (Wo Wv)^T + (Wo bv + bo)
+        const HostW* wo = pk.get(p + "cross_attn_image.out_proj.weight"); const HostW* bo = pk.get(p + "cross_attn_image.out_proj.bias");
+        const HostW* wv = pk.get(p + "cross_attn_image.v_proj.weight"); const HostW* bv = pk.get(p + "cross_attn_image.v_proj.bias");
+        if (wo && bo && wv && bv && wo->data.size() == (size_t)256 * 256 && wv->data.size() == (size_t)256 * 64) {
+          std::vector<float> W((size_t)256 * 64), B(256);
+          for (int n = 0; n < 256; ++n) {
+            double bb = bo->data[n];
+            for (int j = 0; j < 256; ++j) bb += (double)wo->data[(size_t)n * 256 + j] * bv->data[j];
+            B[n] = (float)bb;
+            for (int k = 0; k < 64; ++k) {
+              double a = 0.0;
+              for (int j = 0; j < 256; ++j) a += (double)wo->data[(size_t)n * 256 + j] * wv->data[(size_t)j * 64 + k];
+              W[(size_t)n * 64 + k] = (float)a;
+            }
+          }
+          m.cross_vo = pk.lin16_raw(W, B, 256, 64);
+        }
+      }
       ctx->mal.push_back(m);
       ks.push_back(p + "cross_attn_image.k_proj");
       vs.push_back(p + "cross_attn_image.v_proj");
@@ -1067,6 +1092,7 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ARENA16(ctx->t_vin16, (size_t)TRACK_MAX_N * NKCAP * 64);
   ARENA16(ctx->t_kall16, (size_t)TRACK_MAX_N * NKCAP * 1024);
   ARENA16(ctx->t_vTall16, (size_t)TRACK_MAX_N * 1024 * NKCAP);
+  ARENA16(ctx->t_vinT16, (size_t)TRACK_MAX_N * 64 * NKCAP);
   ALLOC(ctx->t_opart, float, (size_t)16 * 4096 * 256);
   ALLOC(ctx->d_fill_tmp, float, (size_t)65536);
   ALLOC(ctx->d_mask256, float, (size_t)65536);

@@ -39,7 +39,8 @@ static int attn_tail(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& f, co
   memset(&r, 0, sizeof(r));
   r.o_part = f.o_part; r.ml_part = f.ml_part; r.splits = f.splits; r.part_rows = f.Nq;
   r.w = out_proj.w; r.bias = out_proj.b; r.res = x; r.out32 = x; r.ln_w = ln.w; r.ln_b = ln.b; r.eps = 1e-5f; r.out16 = h16; r.ld16 = 256; r.M = f.Nq;
-  if (out_proj.N != 256 || out_proj.K != 256) return sam2mi_set_error(ctx, "attn_tail", "out-projection is not 256 x 256");
+  r.kc = f.dv == 64 ? 64 : 256;
+  if (out_proj.N != 256 || out_proj.K != r.kc) return sam2mi_set_error(ctx, "attn_tail", "out-projection is not 256 x 256 (256 x 64 with the values in the memory space)");
   return run_rowln(ctx, s, r);
 }
 
@@ -52,6 +53,9 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
   const size_t cap = (size_t)ctx->t_nk_cap;
   float* x = ctx->t_x;
   const bool fused_tail = ctx->use_rowln;      // f16x3: split operands, the three-kernel tail
+  // values in the memory space: the cross-attention multiplies its probabilities with the 64-channel memory tokens themselves
+  // (flash256 DV = 64) and gemm_rowln applies Wo Wv behind it - no V projection of the bank, a quarter of the P.V products
+  const bool msv = fused_tail && ctx->use_mem_space_values && ctx->mal[0].cross_vo.w != nullptr;
   for (int n = 0; n < N; ++n) {
     if (Nk[n] <= 0 || ceil32(Nk[n]) > ctx->t_nk_cap) return sam2mi_set_error(ctx, "memattn_forward", "memory length out of range");
     // x = curr + 0.1 * curr_pos   (pos_enc_at_input, :319-321)
@@ -61,9 +65,13 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
     p.out16 = ctx->t_kall16 + n * cap * 1024; p.ld16 = 1024;
     p.rope_cos = ctx->rope_cos; p.rope_sin = ctx->rope_sin; p.rope_len = S; p.rope_rows = n_rope[n]; p.rope_cols = 1024; p.rope_dim = C;
     CHKI(run_gemm(ctx, s, p));
-    GemmParams q = lin_params(ctx->t_vin16 + n * cap * 64, 64, Nk[n], ctx->cross_v_all);
-    q.n_split = 0; q.outT16 = ctx->t_vTall16 + n * cap * 1024; q.ldT16 = ceil32(Nk[n]);
-    CHKI(run_gemm(ctx, s, q));
+    if (msv) {
+      CHK(transpose_rows64_f16_launch(ctx->t_vin16 + n * cap * 64, ctx->t_vinT16 + n * cap * 64, Nk[n], ceil32(Nk[n]), s));
+    } else {
+      GemmParams q = lin_params(ctx->t_vin16 + n * cap * 64, 64, Nk[n], ctx->cross_v_all);
+      q.n_split = 0; q.outT16 = ctx->t_vTall16 + n * cap * 1024; q.ldT16 = ceil32(Nk[n]);
+      CHKI(run_gemm(ctx, s, q));
+    }
   }
   for (int l = 0; l < 4; ++l) {
     const MemAttnLayerW& L = ctx->mal[l];
@@ -105,10 +113,11 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
       memset(&f, 0, sizeof(f));
       f.q = ctx->t_q16 + (size_t)n * S * C; f.ldq = C; f.k = ctx->t_kall16 + n * cap * 1024 + l * 256; f.ldk = 1024;
       f.vT = ctx->t_vTall16 + n * cap * 1024 + (size_t)l * 256 * NkP; f.ldvT = NkP;
+      if (msv) { f.vT = ctx->t_vinT16 + n * cap * 64; f.dv = 64; }
       f.Nq = S; f.Nk = Nk[n]; f.splits = flash256_pick_splits(S, Nk[n]); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
       f.out = fused_tail ? nullptr : ctx->t_o16 + (size_t)n * S * C; f.ldout = C; f.scale_log2e = LOG2E / 16.f; f.out_lo_off = ctx->lo16;
       CHKI(run_flash256(ctx, s, f));
-      if (fused_tail) CHKI(attn_tail(ctx, s, f, L.cross_out, L.n3, x + (size_t)n * S * C, ctx->t_h16 + (size_t)n * S * C));
+      if (fused_tail) CHKI(attn_tail(ctx, s, f, msv ? L.cross_vo : L.cross_out, L.n3, x + (size_t)n * S * C, ctx->t_h16 + (size_t)n * S * C));
     }
     if (!fused_tail) {
       GemmParams p = lin_params(ctx->t_o16, C, M, L.cross_out);

@@ -73,6 +73,7 @@ struct RowLnParams {
   const float* ln_w; const float* ln_b; float eps;
   half_t* out16; int ld16;           // LayerNorm(out32) * ln_w + ln_b as f16
   int M;                             // multiple of 32
+  int kc;                            // operand channels: 0 / 256, or 64 (a16 [M, 64] / o_part [splits, part_rows, 64], W [256, 64])
 };
 hipError_t gemm_rowln_launch(const RowLnParams& p, hipStream_t stream);
 

@@ -25,10 +25,17 @@
 namespace {
 constexpr int RL_BM = 32, RL_C = 256;
 constexpr int RL_XLD = 264;                               // f32 tile row stride: 4 rows apart = 32 banks apart
-constexpr int RL_A_BYTES = RL_BM * RL_C * 2;              // 16 KiB
 constexpr int RL_X_BYTES = RL_BM * RL_XLD * 4;            // 33 KiB
 
+// KC: channels of the operand (K of the product): 256, or 64 = the flash partials of the cross-attention with the values in the
+// memory space (attn_flash256.hip, DV = 64): W is then Wo Wv [256, 64] and the bias Wo bv + bo, composed at weight-load time
+template <int KC>
 __global__ __launch_bounds__(512) void gemm_rowln_kernel(const RowLnParams p) {
+  constexpr int RL_A_BYTES = RL_BM * KC * 2;              // 16 KiB / 4 KiB
+  constexpr int ROWB = KC * 2;                            // operand tile row bytes
+  constexpr int SWZ = KC / 8 < 16 ? KC / 8 - 1 : 15;      // 16-B chunks of a row are XOR-ed with (row & SWZ)
+  constexpr int NG = KC / 64;                             // f32x4 groups per thread in the combine (16 threads per row)
+  constexpr int KS = KC / 16;                             // k-steps
   __shared__ __attribute__((aligned(16))) char smem[RL_A_BYTES + RL_X_BYTES];
   char* sA = smem;
   float* sX = reinterpret_cast<float*>(smem + RL_A_BYTES);
@@ -38,33 +45,33 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const RowLnParams p) {
   const int m0 = blockIdx.x * RL_BM;
 
   // ---- W fragments: lane holds W[n = 32 w + fr][k = 16 s + 8 fh .. + 8)
-  half8 wf[16];
+  half8 wf[KS];
   {
-    const half_t* wr = p.w + (size_t)(wave * 32 + fr) * RL_C + fh * 8;
+    const half_t* wr = p.w + (size_t)(wave * 32 + fr) * KC + fh * 8;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) wf[s] = *reinterpret_cast<const half8*>(wr + s * 16);
+    for (int s = 0; s < KS; ++s) wf[s] = *reinterpret_cast<const half8*>(wr + s * 16);
   }
   // ---- operand tile -> LDS f16.  Thread: row = tid / 16, 16-B f32 groups (sub + 16 i) (coalesced 256-B segments per row)
   {
     const int row = tid >> 4, sub = tid & 15;
     const size_t m = (size_t)(m0 + row);
     if (p.o_part) {
-      f32x4 acc[4];
+      f32x4 acc[NG];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < NG; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       float mstar = -1e30f;
       for (int s = 0; s < p.splits; ++s) mstar = fmaxf(mstar, p.ml_part[((size_t)s * p.part_rows + m) * 2]);
       float L = 0.f;
       // 8 splits per round, their 32 loads all in flight (a round trip to the memory-side cache per split otherwise)
       for (int s0 = 0; s0 < p.splits; s0 += 8) {
-        f32x4 v[8][4];
+        f32x4 v[8][NG];
         float w[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int s = min(s0 + u, p.splits - 1);
-          const float* op = p.o_part + ((size_t)s * p.part_rows + m) * RL_C;
+          const float* op = p.o_part + ((size_t)s * p.part_rows + m) * KC;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[u][i] = *reinterpret_cast<const f32x4*>(op + (sub + 16 * i) * 4);
+          for (int i = 0; i < NG; ++i) v[u][i] = *reinterpret_cast<const f32x4*>(op + (sub + 16 * i) * 4);
           const float* ml = p.ml_part + ((size_t)s * p.part_rows + m) * 2;
           w[u] = (s0 + u < p.splits) ? exp2f(ml[0] - mstar) : 0.f;
           L += w[u] * ml[1];
@@ -72,25 +79,27 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const RowLnParams p) {
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+          for (int i = 0; i < NG; ++i) {
             acc[i][0] += w[u] * v[u][i][0]; acc[i][1] += w[u] * v[u][i][1]; acc[i][2] += w[u] * v[u][i][2]; acc[i][3] += w[u] * v[u][i][3];
           }
       }
       const float inv = 1.f / L;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NG; ++i) {
         const int g = sub + 16 * i;                                 // f32 group = 4 channels = half a 16-B f16 chunk
         const int chunk = g >> 1;
         const half4 h = {(half_t)(acc[i][0] * inv), (half_t)(acc[i][1] * inv), (half_t)(acc[i][2] * inv), (half_t)(acc[i][3] * inv)};
-        *reinterpret_cast<half4*>(sA + row * 512 + ((chunk ^ (row & 15)) << 4) + (g & 1) * 8) = h;
+        *reinterpret_cast<half4*>(sA + row * ROWB + ((chunk ^ (row & SWZ)) << 4) + (g & 1) * 8) = h;
       }
     } else {
       const half_t* ar = p.a16 + m * p.lda;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int chunk = sub + 16 * i;
-        const half8 v = *reinterpret_cast<const half8*>(ar + chunk * 8);
-        *reinterpret_cast<half8*>(sA + row * 512 + ((chunk ^ (row & 15)) << 4)) = v;
+        if (chunk < KC / 8) {
+          const half8 v = *reinterpret_cast<const half8*>(ar + chunk * 8);
+          *reinterpret_cast<half8*>(sA + row * ROWB + ((chunk ^ (row & SWZ)) << 4)) = v;
+        }
       }
     }
   }
@@ -101,14 +110,14 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const RowLnParams p) {
 
   __syncthreads();
 
-  // ---- 32 x 32 per wave, K = 256 (two accumulation chains)
+  // ---- 32 x 32 per wave, K = KC (two accumulation chains)
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
 #pragma unroll
-  for (int s = 0; s < 16; s += 2) {
-    const half8 a0 = *reinterpret_cast<const half8*>(sA + fr * 512 + (((2 * s + fh) ^ (fr & 15)) << 4));
-    const half8 a1 = *reinterpret_cast<const half8*>(sA + fr * 512 + (((2 * s + 2 + fh) ^ (fr & 15)) << 4));
+  for (int s = 0; s < KS; s += 2) {
+    const half8 a0 = *reinterpret_cast<const half8*>(sA + fr * ROWB + (((2 * s + fh) ^ (fr & SWZ)) << 4));
+    const half8 a1 = *reinterpret_cast<const half8*>(sA + fr * ROWB + (((2 * s + 2 + fh) ^ (fr & SWZ)) << 4));
     acc0 = mfma32(a0, wf[s], acc0);
     acc1 = mfma32(a1, wf[s + 1], acc1);
   }
@@ -149,6 +158,8 @@ __global__ __launch_bounds__(512) void gemm_rowln_kernel(const RowLnParams p) {
 hipError_t gemm_rowln_launch(const RowLnParams& p, hipStream_t s) {
   if (p.M <= 0 || p.M % RL_BM || !p.w || !p.res || !p.out32 || !p.out16 || !p.ln_w || !p.ln_b || (p.ld16 & 3)) return hipErrorInvalidValue;
   if (p.o_part ? (!p.ml_part || p.splits < 1 || p.part_rows < p.M) : (!p.a16 || (p.lda & 7))) return hipErrorInvalidValue;
-  gemm_rowln_kernel<<<dim3(p.M / RL_BM), dim3(512), 0, s>>>(p);
+  if (p.kc == 64) gemm_rowln_kernel<64><<<dim3(p.M / RL_BM), dim3(512), 0, s>>>(p);
+  else if (p.kc == 0 || p.kc == 256) gemm_rowln_kernel<256><<<dim3(p.M / RL_BM), dim3(512), 0, s>>>(p);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }

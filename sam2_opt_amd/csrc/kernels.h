@@ -20,6 +20,8 @@ hipError_t im2col_patch_launch(const float* img, int B, int S, half_t* A, hipStr
 hipError_t im2col_patch_u8_launch(const uint8_t* img_hwc, int B, int S, half_t* A, hipStream_t s, size_t lo_off = 0, int row_major = 0);
 // 2x2 max-pool inside w x w windows of window-major tokens: in [nwin*w*w, C] -> out [nwin*(w/2)^2, C]
 hipError_t pool_tokens_f32_launch(const float* in, int ldin, float* out, int ldout, int nwin, int w, int C, hipStream_t s);
+// in [R, 64] f16 -> out [64, ld] (out[c][r] = in[r][c]; columns R .. ld - 1 are written as zeros)
+hipError_t transpose_rows64_f16_launch(const half_t* in, half_t* out, int R, int ld, hipStream_t s);
 hipError_t pool_tokens_split_launch(const half_t* in, size_t in_lo, int ldin, half_t* out, size_t out_lo, int ldout, int nwin, int w, int C, hipStream_t s);
 hipError_t pool_tokens_f16_launch(const half_t* in, int ldin, half_t* out, int ldout, int nwin, int w, int C, hipStream_t s);
 // reorder tokens of B grids (H x W) from window size w_in to window size w_out (w == W means row-major);

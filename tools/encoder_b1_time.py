@@ -5,7 +5,7 @@ from sam2_opt_amd.native import Engine
 from sam2_opt_amd.config import get_config
 from sam2_opt_amd.weights import synthetic_state_dict
 cfg = get_config("large")
-eng = Engine(cfg, state_dict=synthetic_state_dict(cfg, seed=0), max_batch=int(os.environ.get("B", "1")))
+eng = Engine(cfg, state_dict=synthetic_state_dict(cfg, seed=0), max_batch=int(os.environ.get("B", "1")), precision=os.environ.get("PRECISION", "f16s"))
 B = int(os.environ.get("B", "1"))
 x = torch.randn(B, 3, 1024, 1024, device="cuda")
 for _ in range(3):
