@@ -64,8 +64,10 @@ struct Flash256Params {
                                 //   applied by the consumer), o_part [splits, Nq, 64]; partials only (out must be null)
 };
 hipError_t flash256_launch(const Flash256Params& p, hipStream_t stream);
+const char* flash256_kernel_name(const Flash256Params& p);
 hipError_t flash256_init();   // dynamic-LDS attribute, once
-int flash256_pick_splits(int Nq, int Nk);   // KV splits that fill the chip once (<= 16: the size of the partial buffers)
+int flash256_pick_splits(int Nq, int Nk);
+int flash256_pick_splits_dv64(int Nq, int Nk);   // the DV = 64 variant (two workgroups per CU)   // KV splits that fill the chip once (<= 16: the size of the partial buffers)
 
 // ---- tiny fp32 attentions of the two-way mask decoder (attn_small.hip)
 // scratch (optional): partial results of the token -> image kernel that handles all T <= 8 queries of a prompt per workgroup

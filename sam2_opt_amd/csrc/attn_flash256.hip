@@ -196,7 +196,7 @@ static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt
 // memory tokens themselves - a quarter of the P.V products, of the V^T tile bytes in LDS and of the O accumulators - and the consumer
 // (gemm_rowln.hip, KC = 64) applies Wo Wv and Wo bv + bo composed at weight-load time.  Scores keep their 256 channels.)
 template <int ABL, bool MASK, int NST, int DV = 256>
-__global__ __launch_bounds__(256, 1) void flash256_v3_kernel(const Flash256Params p) {
+__global__ __launch_bounds__(256, DV == 64 ? 2 : 1) void flash256_v3_kernel(const Flash256Params p) {
   constexpr int STAGE_BYTES = K3_TILE_B + DV * 64;     // K image + V^T image [DV][32 keys]
   constexpr int VPW = DV / 64;                         // V^T pieces (16 d rows x 64 B) per wave and tile: 4 or 1
   constexpr int PPT = 4 + VPW;                         // LDS-DMA pieces per wave and tile
@@ -700,7 +700,8 @@ hipError_t flash256_init() {
     if (e != hipSuccess) return e;
   }
 #endif
-  for (const void* f : {reinterpret_cast<const void*>(&flash256_v3_kernel<0, false, 4, 64>), reinterpret_cast<const void*>(&flash256_v3_kernel<0, true, 4, 64>)}) {
+  for (const void* f : {reinterpret_cast<const void*>(&flash256_v3_kernel<0, false, 4, 64>), reinterpret_cast<const void*>(&flash256_v3_kernel<0, true, 4, 64>),
+                        reinterpret_cast<const void*>(&flash256_v3_kernel<0, false, 3, 64>), reinterpret_cast<const void*>(&flash256_v3_kernel<0, true, 3, 64>)}) {
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, NST_MAX * (K3_TILE_B + 64 * 64));
     if (e != hipSuccess) return e;
   }
@@ -720,6 +721,16 @@ bool flash256_use_v4(int Nq, int Nk) {
 }
 
 // one workgroup per CU: pick the KV split count that makes the grid one full wave of 256 workgroups
+// DV = 64 runs two workgroups per CU: twice the splits (<= 16, the size of the partial buffers)
+int flash256_pick_splits_dv64(int Nq, int Nk) {
+  static const int wgs = getenv("SAM2MI_FLASH64_WGS") ? atoi(getenv("SAM2MI_FLASH64_WGS")) : 512;
+  const int tiles = (Nk + 31) / 32, qblocks = Nq / 128 > 0 ? Nq / 128 : 1;
+  int s = (wgs + qblocks - 1) / qblocks;
+  if (s > 16) s = 16;
+  if (s > tiles) s = tiles;
+  return s < 1 ? 1 : s;
+}
+
 int flash256_pick_splits(int Nq, int Nk) {
   const int qb = flash256_use_v4(Nq, Nk) ? 256 : 128;
   const int tiles = (Nk + 31) / 32, qblocks = Nq / qb > 0 ? Nq / qb : 1;
@@ -734,14 +745,32 @@ int flash256_pick_splits(int Nq, int Nk) {
   return s < 1 ? 1 : s;
 }
 
+// the instantiation flash256_launch picks, under the name rocprofv3 prints (profiling accumulators)
+const char* flash256_kernel_name(const Flash256Params& p) {
+  const bool mask = (p.Nk % 32) != 0;
+  if (p.dv == 64) {
+    static const int nst = getenv("SAM2MI_FLASH64_STAGES") ? atoi(getenv("SAM2MI_FLASH64_STAGES")) : 3;
+    if (nst == 4) return mask ? "flash256_v3_kernel<0, true, 4, 64>" : "flash256_v3_kernel<0, false, 4, 64>";
+    return mask ? "flash256_v3_kernel<0, true, 3, 64>" : "flash256_v3_kernel<0, false, 3, 64>";
+  }
+  return mask ? "flash256_v3_kernel<0, true, 4, 256>" : "flash256_v3_kernel<0, false, 4, 256>";
+}
+
 hipError_t flash256_launch(const Flash256Params& p, hipStream_t stream) {
   if (p.Nq % 128 || p.Nk <= 0 || p.splits <= 0 || (p.ldq & 7) || (p.ldk & 7) || (p.ldvT & 7) || (p.ldout & 3)) return hipErrorInvalidValue;
   const dim3 grid((p.Nq / 128) * p.splits), block(256);
   if (p.dv == 64) {                 // values in the 64-channel memory space (cross-attention of the memory attention); partials only
     if (p.out) return hipErrorInvalidValue;
-    const size_t lds = (size_t)4 * (K3_TILE_B + 64 * 64);
-    if (p.Nk % 32) flash256_v3_kernel<0, true, 4, 64><<<grid, block, lds, stream>>>(p);
-    else flash256_v3_kernel<0, false, 4, 64><<<grid, block, lds, stream>>>(p);
+    // 3 ring stages (63 KB) and <= 256 registers: two workgroups per CU, i.e. two waves per SIMD hide each other's waits
+    static const int nst = getenv("SAM2MI_FLASH64_STAGES") ? atoi(getenv("SAM2MI_FLASH64_STAGES")) : 3;
+    const size_t lds = (size_t)(nst == 4 ? 4 : 3) * (K3_TILE_B + 64 * 64);
+    if (nst == 4) {
+      if (p.Nk % 32) flash256_v3_kernel<0, true, 4, 64><<<grid, block, lds, stream>>>(p);
+      else flash256_v3_kernel<0, false, 4, 64><<<grid, block, lds, stream>>>(p);
+    } else {
+      if (p.Nk % 32) flash256_v3_kernel<0, true, 3, 64><<<grid, block, lds, stream>>>(p);
+      else flash256_v3_kernel<0, false, 3, 64><<<grid, block, lds, stream>>>(p);
+    }
     return hipGetLastError();
   }
   if (p.dv != 0 && p.dv != 256) return hipErrorInvalidValue;

@@ -244,8 +244,7 @@ int run_flash256(sam2mi_ctx* ctx, hipStream_t s, const Flash256Params& p) {
   // algorithmic bytes: q, K, V^T in (f16), the un-normalised f32 partial outputs + their (max, sum) pairs out (one set per KV split)
   if (ctx->prof_on) {
     const double dv = p.dv == 64 ? 64.0 : 256.0;
-    const char* nm = p.dv == 64 ? ((p.Nk % 32) ? "flash256_v3_kernel<0, true, 4, 64>" : "flash256_v3_kernel<0, false, 4, 64>")
-                                : ((p.Nk % 32) ? "flash256_v3_kernel<0, true, 4, 256>" : "flash256_v3_kernel<0, false, 4, 256>");
+    const char* nm = flash256_kernel_name(p);
     prof_end_named(ctx, ctx->prof_attn, nm, s, e0, e1, 2.0 * p.Nq * (double)p.Nk * (256.0 + dv),
                    512.0 * p.Nq + 2.0 * p.Nk * (256.0 + dv) + (double)p.splits * p.Nq * (dv * 4 + 8));
   }

@@ -114,7 +114,7 @@ int memattn_forward(sam2mi_ctx* ctx, hipStream_t s, const float* curr, const flo
       f.q = ctx->t_q16 + (size_t)n * S * C; f.ldq = C; f.k = ctx->t_kall16 + n * cap * 1024 + l * 256; f.ldk = 1024;
       f.vT = ctx->t_vTall16 + n * cap * 1024 + (size_t)l * 256 * NkP; f.ldvT = NkP;
       if (msv) { f.vT = ctx->t_vinT16 + n * cap * 64; f.dv = 64; }
-      f.Nq = S; f.Nk = Nk[n]; f.splits = flash256_pick_splits(S, Nk[n]); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
+      f.Nq = S; f.Nk = Nk[n]; f.splits = msv ? flash256_pick_splits_dv64(S, Nk[n]) : flash256_pick_splits(S, Nk[n]); f.o_part = ctx->t_opart; f.ml_part = ctx->t_ml;
       f.out = fused_tail ? nullptr : ctx->t_o16 + (size_t)n * S * C; f.ldout = C; f.scale_log2e = LOG2E / 16.f; f.out_lo_off = ctx->lo16;
       CHKI(run_flash256(ctx, s, f));
       if (fused_tail) CHKI(attn_tail(ctx, s, f, msv ? L.cross_vo : L.cross_out, L.n3, x + (size_t)n * S * C, ctx->t_h16 + (size_t)n * S * C));
