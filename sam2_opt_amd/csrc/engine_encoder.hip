@@ -57,7 +57,10 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
     }
   }
   // f16s: attention takes q / k as f16 hi + lo planes (three products for the scores) and V^T as plain f16 (attn_hiera.hip, SPLIT)
-  const bool split_attn = ctx->selective && ctx->split_attn && (M & 7) == 0;
+  const int astage = b.dim_out >= 1152 ? 4 : b.dim_out >= 576 ? 3 : b.dim_out >= 288 ? 2 : 1;
+  const bool plain_attn = ctx->selective && ctx->split_attn && (M & 7) == 0 && !b.q_pool && plan_prec(ctx, b, LIN_PROJ) != PREC_FULL &&
+                          ((b.window == 0 && !ctx->split_attn_global) || !ctx->split_attn_stage[astage]);      // plain f16 q / k where the plan says so
+  const bool split_attn = ctx->selective && ctx->split_attn && (M & 7) == 0 && !plain_attn;
   // 2. QKV projection: q|k row-major, v transposed (attention consumes V^T tiles)
   {
     GemmParams p = qkv_p;
@@ -66,8 +69,9 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
     p.col_scale = b.qscale;                 // q pre-scaled (f32, before the f16 rounding) for the exp2-domain softmax
     p.xs_scale_cols = Co;                   // k / v columns have scale 1
     p.prec = plan_prec(ctx, b, LIN_QKV);
-    p.outT_hi_only = split_attn;
-    if (ctx->precise && !split_attn) {      // f16x3 mode: the attention kernel takes f32 q / k / V^T and splits them itself
+    p.outT_hi_only = split_attn || plain_attn;
+    p.no_out_lo = plain_attn;
+    if (ctx->precise && !split_attn && !plain_attn) {      // f16x3 mode: the attention kernel takes f32 q / k / V^T and splits them itself
       p.out32 = ctx->ws_qk32; p.ld32 = 2 * Co;
       p.outT32 = ctx->ws_vT32; p.ldT32 = M;
     } else {
@@ -77,7 +81,7 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
     CHKI(run_gemm(ctx, s, p));
   }
   // 3. attention
-  if (ctx->precise && !split_attn) {
+  if (ctx->precise && !split_attn && !plain_attn) {
     PreciseAttnParams a;
     memset(&a, 0, sizeof(a));
     a.k = ctx->ws_qk32 + Co; a.ldk = 2 * Co;
