@@ -200,7 +200,7 @@ struct sam2mi_ctx {
   int plan_grp[4] = {3, 3, 3, 3};      // GRP_*: linears outside the Hiera blocks
   bool split_attn = true;
   bool split_attn_global = false;   // ... also in the three global-attention blocks (plan key "gattn"; off: 4,096-key soft-maxes average the q / k rounding out)
-  bool split_attn_stage[5] = {true, true, true, false, false};    // ... per Hiera stage (plan keys "attn1" .. "attn4"): off = plain f16 q / k
+  bool split_attn_stage[5] = {true, true, false, false, false};    // ... per Hiera stage (plan keys "attn1" .. "attn4"): off = plain f16 q / k
                                     // (stages 3-4 off: 256-key windows average the rounding out - 7.59e-4 / 6.69e-4 vs 7.59e-4 / 6.38e-4 on the
                                     // golden, 6.07e-4 / 5.28e-4 on the second one, +4.7 % frames/s; stages 1-2 keep it: 16- and 64-key windows)
   size_t lo16 = 0;

@@ -409,7 +409,7 @@ static bool f16s_plan_init(sam2mi_ctx* ctx) {
       int v;
       if (st == 4) v = PREC_F16;
       else if (k == LIN_FC1 || k == LIN_FC2) v = PREC_F16;               // the MLPs (2/3 of the encoder's FLOPs) as in the f16 mode
-      else if (k == LIN_PROJ && st <= 2) v = PREC_FULL;                  // attention output of stages 1-2: x and W
+      else if (k == LIN_PROJ && st == 1) v = PREC_FULL;                  // attention output of stage 1: x and W (W only: 8.2e-4 / 7.2e-4)
       else v = PREC_WSPLIT;                                              // QKV, stage-3 projection, transition shortcuts: W
       ctx->plan[st][k] = v;
     }
@@ -419,8 +419,10 @@ static bool f16s_plan_init(sam2mi_ctx* ctx) {
   ctx->plan_grp[GRP_MA] = ctx->plan_grp[GRP_MENC] = PREC_F16;
   ctx->split_attn = true;
   ctx->split_attn_global = false;         // measured: 7.59e-4 / 6.38e-4 vs 7.53e-4 / 6.47e-4 with it, +2.1 % frames/s
-  ctx->split_attn_stage[1] = ctx->split_attn_stage[2] = true;
-  ctx->split_attn_stage[3] = ctx->split_attn_stage[4] = false;
+  // q / k split: stage 1 only (8 x 8 windows of 64 keys feeding a fully split projection); stage 2 without it and with a W-only
+  // projection measured 7.47e-4 / 6.32e-4 (second golden 6.31e-4 / 5.51e-4) against 7.59e-4 / 6.69e-4 with both
+  ctx->split_attn_stage[1] = true;
+  ctx->split_attn_stage[2] = ctx->split_attn_stage[3] = ctx->split_attn_stage[4] = false;
   const char* e = getenv("SAM2MI_F16S_PLAN");
   if (!e) return true;
   std::string str(e);
