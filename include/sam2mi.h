@@ -45,10 +45,10 @@ typedef struct sam2mi_config {
                               * reference's fp32 torch path; SAM2MI_PRECISION_F16X3 (1): every MFMA operand is carried as a
                               * 2-term f16 split (hi + lo) and every product costs three MFMAs - the north-star "within 1e-3"
                               * class (measured <= 1e-4 per plug), about 2-3x the MFMA work;
-                              * SAM2MI_PRECISION_F16S (2): SELECTIVE split - the same "within 1e-3" class at a fraction of the
-                              * cost: only the operands whose rounding carries the error are split (weights of the encoder's
-                              * attention linears and of stages 1-2, the attention output and q / k; every linear of the
-                              * tracking path), the rest runs as in the f16 mode (tools/precision_shares.py) */
+                              * SAM2MI_PRECISION_F16S (2): SELECTIVE split - the same "within 1e-3" class at 0.87x the f16 rate:
+                              * only the operands whose rounding carries the error are split (weights of the encoder's QKV and
+                              * output projections, q / k of the stage-1 attention, patch embedding / neck / mask decoder), the
+                              * rest runs as in the f16 mode (measured plan: engine_core.hip f16s_plan_init) */
 } sam2mi_config;
 #define SAM2MI_PRECISION_F16 0
 #define SAM2MI_PRECISION_F16X3 1

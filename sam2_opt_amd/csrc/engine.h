@@ -197,6 +197,7 @@ struct sam2mi_ctx {
   // split q / k (attn_hiera.hip) instead of attn_precise.hip.  Defaults in engine_core.hip (sam2mi_create); SAM2MI_F16S_PLAN overrides
   // entries for precision experiments ("s3.qkv=f16,s12.all=w,other=f16,attn=0"; tools/f16s_plan_sweep.sh).
   int plan[5][5] = {};
+  signed char plan_blk[64][5];      // per-block overrides of plan[][] (-1: none); plan keys "b<lo>-<hi>.<kind>"
   int plan_grp[4] = {3, 3, 3, 3};      // GRP_*: linears outside the Hiera blocks
   bool split_attn = true;
   bool split_attn_global = false;   // ... also in the three global-attention blocks (plan key "gattn"; off: 4,096-key soft-maxes average the q / k rounding out)

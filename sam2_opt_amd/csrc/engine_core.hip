@@ -404,6 +404,7 @@ extern "C" int sam2mi_abi_version(void) { return 2; }      // 2: sam2mi_config.p
 // attention output that feeds the projection (near-uniform attention makes it coherent inside a window), of q / k; stages 1-2
 // and the attention linears of stage 3 matter, the MLP of stage 3 (2/3 of the encoder's FLOPs) and stage 4 hardly do.
 static bool f16s_plan_init(sam2mi_ctx* ctx) {
+  memset(ctx->plan_blk, -1, sizeof(ctx->plan_blk));
   for (int st = 1; st <= 4; ++st)
     for (int k = 0; k < 5; ++k) {
       int v;
@@ -450,6 +451,14 @@ static bool f16s_plan_init(sam2mi_ctx* ctx) {
     if (dot == std::string::npos) return false;
     const std::string sc = key.substr(0, dot), kd = key.substr(dot + 1);
     int s0, s1;
+    int b0 = -1, b1 = -1;
+    if (sc.size() >= 2 && sc[0] == 'b' && isdigit((unsigned char)sc[1])) {             // b<lo>-<hi> / b<n>: block range
+      const size_t dash = sc.find('-');
+      b0 = atoi(sc.c_str() + 1);
+      b1 = dash == std::string::npos ? b0 : atoi(sc.c_str() + dash + 1);
+      if (b0 < 0 || b1 < b0 || b1 >= 64) return false;
+      s0 = s1 = 0;
+    } else
     if (sc == "s1") s0 = s1 = 1;
     else if (sc == "s2") s0 = s1 = 2;
     else if (sc == "s12") { s0 = 1; s1 = 2; }
@@ -465,6 +474,11 @@ static bool f16s_plan_init(sam2mi_ctx* ctx) {
     else if (kd == "mlp") { k0 = LIN_FC1; k1 = LIN_FC2; }
     else if (kd == "all") { k0 = 0; k1 = 4; }
     else return false;
+    if (b0 >= 0) {
+      for (int bi = b0; bi <= b1; ++bi)
+        for (int k = k0; k <= k1; ++k) ctx->plan_blk[bi][k] = (signed char)v;
+      continue;
+    }
     for (int st = s0; st <= s1; ++st)
       for (int k = k0; k <= k1; ++k) ctx->plan[st][k] = v;
   }

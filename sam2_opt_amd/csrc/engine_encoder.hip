@@ -20,6 +20,7 @@ static const float LOG2E = 1.4426950408889634f;
 static int plan_prec(const sam2mi_ctx* ctx, const HieraBlockW& b, int kind) {
   if (!ctx->selective) return PREC_AUTO;
   const int stage = b.dim_out >= 1152 ? 4 : b.dim_out >= 576 ? 3 : b.dim_out >= 288 ? 2 : 1;
+  if (b.idx >= 0 && b.idx < 64 && ctx->plan_blk[b.idx][kind] >= 0) return ctx->plan_blk[b.idx][kind];
   return ctx->plan[stage][kind];
 }
 

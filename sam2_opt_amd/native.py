@@ -102,8 +102,8 @@ class Engine:
                  feat_slots: int = 16, device: Optional[torch.device] = None, precision: str = "f16"):
         """`precision` (include/sam2mi.h): "f16" (plain f16 MFMA operands, f32 accumulation: the bf16-class tier, ~2e-3 of the
         reference's fp32 path), "f16s" (selective 2-term f16 split of the operands whose rounding carries the error: masks within 1e-3 at
-        0.80x the f16 rate; what bench.py and plugin.speedup_hip use by default), "f16x3" (every operand split, three MFMAs per product:
-        ~1e-5 at 0.38x).  The split modes exist for hiera-large only."""
+        0.87x the f16 rate; what bench.py and plugin.speedup_hip use by default), "f16x3" (every operand split, three MFMAs per product:
+        ~1e-5 at 0.36x).  The split modes exist for hiera-large only."""
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
         self.precision = precision
