@@ -349,7 +349,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=100)
     ap.add_argument("--encode-batch", type=int, default=8)
-    ap.add_argument("--prefetch-depth", type=int, default=1, help="encoder batches the prefetch stream may run ahead of the tracking")
+    ap.add_argument("--prefetch-depth", type=int, default=2, help="encoder batches the prefetch stream may run ahead of the tracking")
     ap.add_argument("--no-overlap", action="store_true", help="encode and track on one stream (no encoder prefetch stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

@@ -52,7 +52,7 @@ class SAM2VideoPredictor:
                  encode_batch: int = 8, bank_slots: int = 384, fill_hole_area: int = 0, non_overlap_masks: bool = False,
                  overlap_encode: bool = True, precision: Optional[str] = None, clear_non_cond_mem_around_input: bool = False,
                  add_all_frames_to_correct_as_cond: bool = False, max_cond_frames_in_attn: int = -1,
-                 memory_temporal_stride_for_eval: int = 1, prefetch_depth: int = 1):
+                 memory_temporal_stride_for_eval: int = 1, prefetch_depth: int = 2):
         self.cfg = get_config(model)
         if state_dict is None and ckpt_path is not None:
             # same contract as build_sam._load_checkpoint (build_sam.py:164-174)

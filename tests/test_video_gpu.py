@@ -596,7 +596,7 @@ def test_direction_change_keeps_the_frames_about_to_be_tracked_cached(sd_large):
     from sam2_opt_amd.synthetic import synthetic_frames_u8
     from sam2_opt_amd.video_predictor import SAM2VideoPredictor
     u8 = synthetic_frames_u8(seed=22, num_frames=20)
-    p = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4)            # 8 feature slots
+    p = SAM2VideoPredictor("large", state_dict=sd_large, encode_batch=4, prefetch_depth=1)            # 8 feature slots
     try:
         st = p.init_state(frames_u8=u8, video_height=1024, video_width=1024)
         p.add_new_points_or_box(st, 10, 1, points=np.array([CLICK], np.float32), labels=np.array([1], np.int32))
