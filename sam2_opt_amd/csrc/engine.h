@@ -49,6 +49,7 @@ struct HieraBlockW {
   bool q_pool, stage_end;
   Norm n1, n2;
   Lin16 qkv, proj, fc1, fc2, sc;   // sc: dim-change shortcut projection (blocks 2, 8, 44)
+  half_t* proj_pack_lo = nullptr;  // ... of the weight's lo plane (f16s mode: split projection + norm2 in one launch, stages 1-2)
   half_t* proj_pack = nullptr;     // proj in the X-stationary piece order, for gemm_projln_kernel (proj + residual + norm2 in one launch)
   half_t* mlp_pack = nullptr;      // fc1 + fc2 in the fused MLP kernel's piece order (dim_out <= 288), mlp_fused_pack
   half_t* mlp_ln_pack = nullptr;   // the same with norm2 folded into fc1 (LN-fused operand load); fc1 bias = fc1.b_ln

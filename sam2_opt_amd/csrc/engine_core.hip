@@ -230,7 +230,7 @@ int run_projln(sam2mi_ctx* ctx, hipStream_t s, const ProjLnParams& p) {
   CHK(gemm_projln_launch(p, s));
   if (ctx->prof_on) {
     char nm[64];
-    snprintf(nm, sizeof(nm), "gemm_projln_kernel<%d>", p.C);
+    snprintf(nm, sizeof(nm), p.wpack_lo ? "gemm_projln_kernel<%d, %d>" : "gemm_projln_kernel<%d>", p.C, p.a_lo_off ? 3 : 2);
     // algorithmic bytes: f16 operand + weights + f32 residual in and out + f16 LayerNorm output
     prof_end_named(ctx, ctx->prof_gemm, nm, s, e0, e1, 2.0 * p.M * (double)p.C * p.C, (double)p.M * p.C * (2 + 4 + 4 + 2) + 2.0 * p.C * p.C);
   }
@@ -512,7 +512,7 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   ctx->use_fused_mlp = (!ctx->precise || ctx->selective) && getenv("SAM2MI_NO_FUSED_MLP") == nullptr;      // f16s: where the plan has both MLP linears in f16
   ctx->use_xs = (!ctx->precise || ctx->selective) && getenv("SAM2MI_NO_XS") == nullptr;      // f16s: the linears planned as plain f16
   ctx->use_rowln = (!ctx->precise || (ctx->selective && ctx->plan_grp[GRP_MA] == PREC_F16)) && getenv("SAM2MI_NO_ROWLN") == nullptr;
-  ctx->use_projln = !ctx->precise && getenv("SAM2MI_NO_PROJLN") == nullptr;
+  ctx->use_projln = (!ctx->precise || ctx->selective) && getenv("SAM2MI_NO_PROJLN") == nullptr;      // f16s: the split instantiations, stages 1-2
   ctx->use_mem_space_values = getenv("SAM2MI_NO_MEM_SPACE_VALUES") == nullptr;      // A/B switch (needs the fused tail)
   // norm1 inside the operand load of the X-stationary QKV kernel: pays in stage 1 only (C = 144: the QKV launch goes 162 -> 200 us and the
   // 107-us LayerNorm launch disappears; same box, 8-frame pass 28.14 -> 27.89 ms with 144, 27.98 with 288, worse with 576)
@@ -697,9 +697,15 @@ extern "C" int sam2mi_finalize_weights(sam2mi_ctx* ctx) {
       // stages 1-2 only by default: at C = 576 a 32-row workgroup streams the whole 663-KB weight from L2 with 9 KB per wave in flight
       // and takes 89 us where GEMM + LayerNorm take 55 + 21 (C = 144: 184 vs 198 + 107 us, C = 288: 94 vs 106 + 41 us)
       static const int projln_max_c = getenv("SAM2MI_PROJLN_MAXC") ? atoi(getenv("SAM2MI_PROJLN_MAXC")) : 288;
-      if (pk.ok && !ctx->precise && b.proj.w && b.proj.N == dim_out && b.proj.K == dim_out && gemm_projln_supported(dim_out) && dim_out <= projln_max_c) {
+      const int pst = dim_out >= 1152 ? 4 : dim_out >= 576 ? 3 : dim_out >= 288 ? 2 : 1;
+      const bool projln_split = ctx->selective && dim_out <= 288 && b.proj.lo_off && ctx->plan[pst][LIN_PROJ] >= PREC_WSPLIT;      // f16s: stages 1-2
+      if (pk.ok && (!ctx->precise || projln_split) && b.proj.w && b.proj.N == dim_out && b.proj.K == dim_out && gemm_projln_supported(dim_out) && dim_out <= projln_max_c) {
         b.proj_pack = (half_t*)dalloc(ctx, gemm_xs_pack_bytes(dim_out, dim_out));      // out-projection + residual + norm2 in one kernel
         if (!b.proj_pack || gemm_xs_pack(b.proj.w, dim_out, dim_out, dim_out, b.proj_pack, nullptr) != hipSuccess) pk.ok = false;
+        if (projln_split) {
+          b.proj_pack_lo = (half_t*)dalloc(ctx, gemm_xs_pack_bytes(dim_out, dim_out));
+          if (!b.proj_pack_lo || gemm_xs_pack(b.proj.w + b.proj.lo_off, dim_out, dim_out, dim_out, b.proj_pack_lo, nullptr) != hipSuccess) pk.ok = false;
+        }
       }
       for (Lin16* L : {&b.fc2}) {       // stage 3 (N = 576, K = 2304): fc2 in the accumulator-stationary kernel's order (the projection, K = 576, is faster tiled)
         if (!pk.ok || ctx->precise || !L->w || !gemm_ks_supported(L->N, L->K)) continue;

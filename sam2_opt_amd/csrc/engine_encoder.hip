@@ -136,9 +136,12 @@ int hiera_block_forward(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, in
   CHKI(run_hiera_attn(ctx, s, a));
   }
   // 4. output projection + residual (+ norm2 in the same kernel where a workgroup can own whole rows: stages 1-3, f16 mode)
-  const bool proj_ln = ctx->use_projln && !ctx->ln_fuse && b.proj_pack && (Mq & 31) == 0;
+  const int pprec = plan_prec(ctx, b, LIN_PROJ);
+  const bool proj_ln = ctx->use_projln && !ctx->ln_fuse && b.proj_pack && (Mq & 31) == 0 &&
+                       (!ctx->selective || (b.proj_pack_lo && (pprec == PREC_WSPLIT || (pprec == PREC_FULL && split_attn))));
   if (proj_ln) {
-    ProjLnParams q{ctx->ws_att16, Co, b.proj_pack, b.proj.b, xres, x, b.n2.w, b.n2.b, 1e-6f, ctx->ws_a16, Co, Mq, Co};
+    ProjLnParams q{ctx->ws_att16, Co, b.proj_pack, b.proj.b, xres, x, b.n2.w, b.n2.b, 1e-6f, ctx->ws_a16, Co, Mq, Co, nullptr, 0};
+    if (ctx->selective) { q.wpack_lo = b.proj_pack_lo; q.a_lo_off = pprec == PREC_FULL ? ctx->lo16 : 0; }
     CHKI(run_projln(ctx, s, q));
   } else {
     GemmParams p = lin_params(ctx->ws_att16, Co, Mq, b.proj);

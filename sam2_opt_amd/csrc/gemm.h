@@ -86,6 +86,9 @@ struct ProjLnParams {
   const float* ln_w; const float* ln_b; float eps;
   half_t* out16; int ld16;           // LayerNorm(out32) * ln_w + ln_b as f16
   int M, C;                          // M % 32 == 0
+  // f16s precision mode (C = 144 / 288): wpack_lo = the packed image of the weight's lo plane (2 MFMAs per fragment pair);
+  // a_lo_off != 0: the operand's lo plane sits that many elements behind a16 (3 MFMAs)
+  const half_t* wpack_lo; size_t a_lo_off;
 };
 bool gemm_projln_supported(int C);
 hipError_t gemm_projln_launch(const ProjLnParams& p, hipStream_t stream);

@@ -16,7 +16,9 @@
 //     288 / 576 / 1152-byte row strides); the f32 result tile re-uses that LDS after the products
 //   * row phase: one wave per row, the layernorm_vec_kernel arithmetic (two-pass mean / variance), residual rows requested before
 //     the barrier in front of it.
-// f16 mode only (the f16x3 mode keeps GEMM + LayerNorm: its operands are split pairs).
+// SP (f16s precision mode): 2 = the weight as a 2-term f16 split (second packed image `wpack_lo`, its products in a second accumulator
+// set folded in x 2^-11), 3 = the operand split as well (lo plane `a_lo_off` elements behind a16: three MFMAs per fragment pair) - the
+// stage-1 / stage-2 projections of the f16s plan.  The f16x3 mode keeps GEMM + LayerNorm.
 #include "gemm.h"
 #include "gemm_xs.h"
 
@@ -33,15 +35,17 @@ struct PL {
   static constexpr int XLD = C + 8;                          // f32 tile row stride: 4 rows apart = 32 banks apart
   static constexpr int A_BYTES = 32 * C * 2, X_BYTES = 32 * XLD * 4;
   static constexpr int LDS_B = A_BYTES > X_BYTES ? A_BYTES : X_BYTES;
+  static constexpr int LDS_B2 = 2 * A_BYTES > X_BYTES ? 2 * A_BYTES : X_BYTES;       // operand split as well: hi tile + lo tile
   static constexpr int VPL = (C / 4 + 63) / 64;              // float4 per lane in the row phase
   static constexpr int RPW = (32 + NW - 1) / NW;             // rows per wave (at most)
   static constexpr int G = 3;                                // k-steps per weight-prefetch group
   static_assert(KS % G == 0, "k-steps per group");
 };
 
-template <int C>
+template <int C, int SP = 0>
 __global__ __launch_bounds__(PL<C>::NW * 64) void gemm_projln_kernel(const ProjLnParams p) {
   using L = PL<C>;
+  constexpr bool WS = SP >= 2, AS = SP == 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];      // L::LDS_B bytes (74,752 at C = 576: dynamic)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -54,37 +58,54 @@ __global__ __launch_bounds__(PL<C>::NW * 64) void gemm_projln_kernel(const ProjL
     const int stage = t / L::CPS, q = (t % L::CPS) * L::KS + s;
     return reinterpret_cast<const half8*>(wp + ((size_t)stage * XS_STAGE_SLOTS + q) * 1024);
   };
-  half8 wa[L::G][L::TPW], wb[L::G][L::TPW];
-  auto load_group = [&](half8 (&w)[L::G][L::TPW], int g) {
+  const long wlo = WS ? reinterpret_cast<const char*>(p.wpack_lo) - reinterpret_cast<const char*>(p.wpack) : 0;      // bytes from a hi piece to its lo piece
+  struct WG { half8 h[L::G][L::TPW]; half8 l[WS ? L::G : 1][WS ? L::TPW : 1]; };
+  WG wa, wb;
+  auto load_group = [&](WG& w, int g) {
 #pragma unroll
     for (int j = 0; j < L::G; ++j)
 #pragma unroll
-      for (int i = 0; i < L::TPW; ++i) w[j][i] = *piece(min(wave * L::TPW + i, L::NT - 1), g * L::G + j);
+      for (int i = 0; i < L::TPW; ++i) {
+        const half8* pp = piece(min(wave * L::TPW + i, L::NT - 1), g * L::G + j);
+        w.h[j][i] = *pp;
+        if constexpr (WS) w.l[j][i] = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(pp) + wlo);
+      }
   };
   load_group(wa, 0);
 
   // ---- operand tile -> LDS (coalesced 16-B pieces, chunk index XOR-ed with the row)
   for (int i = tid; i < 32 * L::CH; i += L::NW * 64) {
     const int row = i / L::CH, ch = i % L::CH;
-    const half8 v = *reinterpret_cast<const half8*>(p.a16 + (size_t)(m0 + row) * p.lda + ch * 8);
-    *reinterpret_cast<half8*>(smem + row * (C * 2) + ((ch ^ ((row >> L::SWZ_SHIFT) & L::SWZ_MASK)) << 4)) = v;
+    const half_t* ap = p.a16 + (size_t)(m0 + row) * p.lda + ch * 8;
+    char* dst = smem + row * (C * 2) + ((ch ^ ((row >> L::SWZ_SHIFT) & L::SWZ_MASK)) << 4);
+    *reinterpret_cast<half8*>(dst) = *reinterpret_cast<const half8*>(ap);
+    if constexpr (AS) *reinterpret_cast<half8*>(dst + L::A_BYTES) = *reinterpret_cast<const half8*>(ap + p.a_lo_off);      // lo tile behind the hi tile
   }
   __syncthreads();
 
-  f32x16 acc[L::TPW];
+  f32x16 acc[L::TPW], accx[WS ? L::TPW : 1];
 #pragma unroll
   for (int i = 0; i < L::TPW; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      acc[i][r] = 0.f;
+      if constexpr (WS) accx[i][r] = 0.f;
+    }
   const char* arow = smem + fr * (C * 2);
   const int aswz = (fr >> L::SWZ_SHIFT) & L::SWZ_MASK;
-  auto mma_group = [&](const half8 (&w)[L::G][L::TPW], int g) {
+  auto mma_group = [&](const WG& w, int g) {
 #pragma unroll
     for (int j = 0; j < L::G; ++j) {
       const int s = g * L::G + j;
       const half8 a = *reinterpret_cast<const half8*>(arow + (((2 * s + fh) ^ aswz) << 4));
+      half8 al;
+      if constexpr (AS) al = *reinterpret_cast<const half8*>(arow + L::A_BYTES + (((2 * s + fh) ^ aswz) << 4));
 #pragma unroll
-      for (int i = 0; i < L::TPW; ++i) acc[i] = mfma32(a, w[j][i], acc[i]);
+      for (int i = 0; i < L::TPW; ++i) {
+        acc[i] = mfma32(a, w.h[j][i], acc[i]);
+        if constexpr (WS) accx[i] = mfma32(a, w.l[j][i], accx[i]);
+        if constexpr (AS) accx[i] = mfma32(al, w.h[j][i], accx[i]);
+      }
     }
   };
   constexpr int NG = L::KS / L::G;
@@ -117,7 +138,7 @@ __global__ __launch_bounds__(PL<C>::NW * 64) void gemm_projln_kernel(const ProjL
     if (wave * L::TPW + i < L::NT && n < C) {
       const float b = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sX[acc_row(r, lane) * L::XLD + n] = acc[i][r] + b;
+      for (int r = 0; r < 16; ++r) sX[acc_row(r, lane) * L::XLD + n] = (WS ? fmaf(accx[i][r], SPLIT_INV, acc[i][r]) : acc[i][r]) + b;
     }
   }
   __syncthreads();
@@ -179,6 +200,10 @@ hipError_t gemm_projln_init() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_projln_kernel<144>), hipFuncAttributeMaxDynamicSharedMemorySize, PL<144>::LDS_B);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_projln_kernel<288>), hipFuncAttributeMaxDynamicSharedMemorySize, PL<288>::LDS_B);
   if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_projln_kernel<576>), hipFuncAttributeMaxDynamicSharedMemorySize, PL<576>::LDS_B);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_projln_kernel<144, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PL<144>::LDS_B);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_projln_kernel<144, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, PL<144>::LDS_B2);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_projln_kernel<288, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PL<288>::LDS_B);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_projln_kernel<288, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, PL<288>::LDS_B2);
   return e;
 }
 
@@ -187,6 +212,17 @@ hipError_t gemm_projln_launch(const ProjLnParams& p, hipStream_t s) {
       !p.out16 || (p.ld16 & 3))
     return hipErrorInvalidValue;
   const dim3 grid(p.M / 32);
+  if (p.wpack_lo) {                    // split modes: stages 1-2 only
+    const bool as = p.a_lo_off != 0;
+    if (p.C == 144) {
+      if (as) gemm_projln_kernel<144, 3><<<grid, dim3(PL<144>::NW * 64), PL<144>::LDS_B2, s>>>(p);
+      else gemm_projln_kernel<144, 2><<<grid, dim3(PL<144>::NW * 64), PL<144>::LDS_B, s>>>(p);
+    } else if (p.C == 288) {
+      if (as) gemm_projln_kernel<288, 3><<<grid, dim3(PL<288>::NW * 64), PL<288>::LDS_B2, s>>>(p);
+      else gemm_projln_kernel<288, 2><<<grid, dim3(PL<288>::NW * 64), PL<288>::LDS_B, s>>>(p);
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   switch (p.C) {
     case 144: gemm_projln_kernel<144><<<grid, dim3(PL<144>::NW * 64), PL<144>::LDS_B, s>>>(p); break;
     case 288: gemm_projln_kernel<288><<<grid, dim3(PL<288>::NW * 64), PL<288>::LDS_B, s>>>(p); break;

@@ -141,6 +141,20 @@ def oracle_enc(sd_large, cfg_large):
     return img, outs, blocks
 
 
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 7, 8, 9, 23, 44, 45])
+def test_hiera_block_f16s(engs, oracle_enc, idx):
+    """One MultiScaleBlock in the f16s mode on the oracle's input for that block: every kernel of the selective plan in its place
+    (weight-split X-stationary QKV, split-q/k attention + fully split projection + norm2 in one launch in stage 1, W-split projection +
+    norm2 in stage 2, plain attention + fused MLP elsewhere).  Per block the mode sits between f16 (2e-3) and f16x3 (1e-6)."""
+    _, _, blocks = oracle_enc
+    if blocks.get(idx - 1) is None:
+        pytest.skip("no oracle input recorded for this block")
+    x = blocks[idx - 1].cuda()
+    ref = blocks[idx]
+    out = engs.debug_hiera_block(idx, x, ref.shape)
+    check(f"f16s hiera block {idx}", out, ref, 1.5e-3, 8e-4)
+
+
 @pytest.mark.parametrize("idx", [0, 2, 3, 8, 9, 23, 44, 45])
 def test_hiera_block_precise(eng3, oracle_enc, idx):
     _, _, blocks = oracle_enc
