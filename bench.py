@@ -266,33 +266,36 @@ def secondary_legs(args, pred, sd, cfg, frames, device):
     # (c) route A: the drop-in route - a torch host loop around the five plug-level entry points in the reference's tensor
     # layouts (sam2_opt_amd/route_a.py), what sam2_opt_amd.plugin.speedup_hip(reference_predictor) pays per frame
     from sam2_opt_amd.route_a import PlugLevelTracker
-    trk = PlugLevelTracker("large", state_dict=sd, device=device, precision=args.precision)
-    try:
-        nA = min(100, frames.shape[0])
-        fa = frames[:nA].to(device)
-        for k in range(2):
-            trk.start(fa, (512.0, 512.0))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n = sum(1 for _ in trk.propagate())
-            torch.cuda.synchronize()
-        out["route_a_frames_per_s"] = round(n / (time.perf_counter() - t0), 2)
-        # BASELINE.json configs[1]: the image-encoder plug alone at batch 1 (what every frame of the drop-in route pays)
-        for _ in range(3):
-            trk.engine.image_encoder(fa[0:1].contiguous())
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            trk.engine.image_encoder(fa[0:1].contiguous())
-        torch.cuda.synchronize()
-        out["config1_image_encoder_batch1_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
-        out["route_a_note"] = (f"plug-level route (image encoder, memory attention, prompt encoder, mask decoder, memory encoder called one by one "
-                               f"per frame with NCHW / sequence-first fp32 tensors, torch glue and memory bank; the image plug looks 8 frames ahead over the clip tensor, "
-                               f"plugin.LookaheadImagePlug): propagate loop over the first {nA} "
-                               f"frames, precision={args.precision}; the headline `value` is the fused route (frame features and memory bank resident "
-                               "in the engine, one C call per tracked frame)")
-    finally:
-        trk.release()
+    nA = min(100, frames.shape[0])
+    fa = frames[:nA].to(device)
+    for prec in dict.fromkeys((args.precision, "f16")):             # the timed mode, and plain f16 beside it
+        trk = PlugLevelTracker("large", state_dict=sd, device=device, precision=prec)
+        try:
+            for k in range(2):
+                trk.start(fa, (512.0, 512.0))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n = sum(1 for _ in trk.propagate())
+                torch.cuda.synchronize()
+            key = "route_a_frames_per_s" if prec == args.precision else f"route_a_{prec}_frames_per_s"
+            out[key] = round(n / (time.perf_counter() - t0), 2)
+            if prec == args.precision:
+                # BASELINE.json configs[1]: the image-encoder plug alone at batch 1 (what a frame costs where the look-ahead cannot apply)
+                for _ in range(3):
+                    trk.engine.image_encoder(fa[0:1].contiguous())
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    trk.engine.image_encoder(fa[0:1].contiguous())
+                torch.cuda.synchronize()
+                out["config1_image_encoder_batch1_ms"] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
+        finally:
+            trk.release()
+    out["route_a_note"] = (f"plug-level route (image encoder, memory attention, prompt encoder, mask decoder, memory encoder called one by one "
+                           f"per frame with NCHW / sequence-first fp32 tensors, torch glue and memory bank; the image plug looks 8 frames ahead over the clip tensor, "
+                           f"plugin.LookaheadImagePlug): propagate loop over the first {nA} "
+                           f"frames, precision={args.precision} (and f16 beside it); the headline `value` is the fused route (frame features and memory bank resident "
+                           "in the engine, one C call per tracked frame)")
     B = 16
     ip = SAM2ImagePredictor("large", state_dict=sd, max_batch=B, device=device, precision=args.precision)
     try:
