@@ -70,6 +70,8 @@ class LookaheadImagePlug:
         self.stream = None
         self.use_side = side_stream
         self.stats = dict(calls=0, hits=0, batches=0, frames_encoded=0)
+        import threading
+        self._lock = threading.RLock()    # one predictor may be driven from several host threads (video_multi_thread.py): calls are serialised
 
     def clear(self):
         self.cache.clear()
@@ -99,6 +101,10 @@ class LookaheadImagePlug:
         return {first_off + k * fe: (tuple(o[k:k + 1] for o in outs), ev) for k in range(n)}
 
     def __call__(self, img: torch.Tensor):
+        with self._lock:
+            return self._call(img)
+
+    def _call(self, img: torch.Tensor):
         self.stats["calls"] += 1
         eng = self.engine
         img = img.to(eng.device, torch.float32)
