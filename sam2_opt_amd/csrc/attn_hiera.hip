@@ -23,7 +23,7 @@ constexpr int REGION = K_TILE + V_TILE;
 // SPLIT (f16s precision mode): q / k as 2-term f16 splits (lo plane qk_lo_off elements behind the hi plane), three products for
 // the scores, output as hi + lo - see hiera_attn_v2_kernel<SPLIT> below; the K_lo tile sits behind the V^T tile of a region.
 template <bool SHARE, bool MASK, bool SPLIT = false>
-__global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p) {
+__global__ __launch_bounds__(256, 2) void hiera_attn_kernel(const HieraAttnParams p) {
   constexpr int REG = REGION + (SPLIT ? K_TILE : 0);
   __shared__ __attribute__((aligned(16))) half_t smem[(SHARE ? 1 : 4) * REG];
   constexpr int NTHR = SHARE ? 256 : 64;
@@ -127,28 +127,46 @@ __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p
     const int k0 = kv_start + kt * 32;
     if (kt + 1 < kv_tiles) gload(k0 + 32);
     // ---- S^T = K Q^T  (32 keys x 32 queries), exp2 domain
+    // the K (and K_lo) fragments of the tile are requested before the score chains, the V^T fragments between the chains and the
+    // softmax arithmetic that covers their latency; the scheduling barriers pin that (left alone the scheduler sinks each ds_read
+    // to its MFMA: one exposed LDS latency per MFMA)
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    constexpr bool KL_UP = SPLIT && SHARE;       // per-wave tiles (!SHARE) stage 58 registers of the next tile: K_lo is read behind the first chain there
+    half8 kf[5], kl[SPLIT ? 5 : 1], vf[3][2];
 #pragma unroll
     for (int ks = 0; ks < 5; ++ks) {
-      const half8 kf = *reinterpret_cast<const half8*>(sK + fr * KROW + ks * 16 + fh * 8);
-      s = mfma32(kf, qf[ks], s);
+      kf[ks] = *reinterpret_cast<const half8*>(sK + fr * KROW + ks * 16 + fh * 8);
+      if (KL_UP) kl[SPLIT ? ks : 0] = *reinterpret_cast<const half8*>(sKl + fr * KROW + ks * 16 + fh * 8);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) s = mfma32(kf[ks], qf[ks], s);
     if (SPLIT) {                    // cross terms in their own chain, folded in x 2^-11
       f32x16 sc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 5; ++ks) {
-        const half8 kf = *reinterpret_cast<const half8*>(sK + fr * KROW + ks * 16 + fh * 8);
-        const half8 kl = *reinterpret_cast<const half8*>(sKl + fr * KROW + ks * 16 + fh * 8);
-        sc = mfma32(kl, qf[ks], sc);
-        sc = mfma32(kf, ql[SPLIT ? ks : 0], sc);
+        if (!KL_UP) kl[SPLIT ? ks : 0] = *reinterpret_cast<const half8*>(sKl + fr * KROW + ks * 16 + fh * 8);
+        sc = mfma32(kf[ks], ql[SPLIT ? ks : 0], sc);
+        sc = mfma32(kl[SPLIT ? ks : 0], qf[ks], sc);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = fmaf(sc[r], SPLIT_INV, s[r]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const half_t* vr = sV + (t * 32 + fr) * VROW + ks * 16 + fh * 4;
+        const half4 lo = *reinterpret_cast<const half4*>(vr);
+        const half4 hi = *reinterpret_cast<const half4*>(vr + 8);
+        vf[t][ks] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    __builtin_amdgcn_sched_barrier(0);
     float tmax = -1e30f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -181,13 +199,7 @@ __global__ __launch_bounds__(256) void hiera_attn_kernel(const HieraAttnParams p
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const half_t* vr = sV + (t * 32 + fr) * VROW + ks * 16 + fh * 4;
-        const half4 lo = *reinterpret_cast<const half4*>(vr);
-        const half4 hi = *reinterpret_cast<const half4*>(vr + 8);
-        const half8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        o[t] = mfma32(vf, pf[ks], o[t]);
-      }
+      for (int ks = 0; ks < 2; ++ks) o[t] = mfma32(vf[t][ks], pf[ks], o[t]);
     }
     __syncthreads();                                  // tile fully consumed
     if (kt + 1 < kv_tiles) swrite();

@@ -255,14 +255,36 @@ __global__ __launch_bounds__(WM * WN * 64, RS ? 4 : (WM * WN > 8 || SPLIT == 1 |
     sync_tile(kt);
     const char* sA = smem + (kt % STAGES) * STAGE;
     const char* sB = sA + A_BYTES;
-    Frag f0 = ldfrag(sA, sB, 0);
-    Frag f1 = ldfrag(sA, sB, 1);
-    mma(f0);
-    f0 = ldfrag(sA, sB, 2);
-    mma(f1);
-    f1 = ldfrag(sA, sB, 3);
-    mma(f0);
-    mma(f1);
+    // Three k-steps of fragments are requested before the first MFMA and the fourth right behind it; the scheduling barriers pin
+    // that order.  Left alone the machine scheduler sinks every ds_read to its use to save registers (86 VGPRs on the 128x192 tile)
+    // and, with an LDS-DMA in flight, hipcc waits lgkmcnt(0) at every use: the loop became read -> wait -> ONE MFMA, twelve exposed
+    // LDS latencies per K tile and wave.  Pinned, a wave waits once at the top of the tile (covered by the other waves of the SIMD) and
+    // once, for reads issued two MFMA groups earlier, before the last k-step.
+    if constexpr (TM * TN <= 4) {
+      Frag f0 = ldfrag(sA, sB, 0);
+      Frag f1 = ldfrag(sA, sB, 1);
+      Frag f2 = ldfrag(sA, sB, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f0);
+      f0 = ldfrag(sA, sB, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f1);
+      mma(f2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f0);
+    } else {                       // six accumulator tiles per wave (256x288): two fragment sets, each k-step's MFMAs cover the next reads
+      Frag f0 = ldfrag(sA, sB, 0);
+      Frag f1 = ldfrag(sA, sB, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f0);
+      f0 = ldfrag(sA, sB, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f1);
+      f1 = ldfrag(sA, sB, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f0);
+      mma(f1);
+    }
   }
   if (nfull < nk) {                                // K tail, executed once
     const int kt = nk - 1;
@@ -462,7 +484,7 @@ hipError_t gemm_v2_init() {
       v2_attr<128, 192, 4, 2, 2, 0, true>(), v2_attr<128, 128, 4, 2, 2, 0, true>(), v2_attr<128, 64, 4, 2, 2, 0, true>(),
       v2_attr<256, 192, 4, 2, 2>(), v2_attr<256, 256, 4, 4, 2>(), v2_attr<256, 192, 4, 3, 2>(), v2_attr<256, 128, 4, 2, 3>(), v2_attr<128, 128, 2, 2, 2>(),
       v2_attr<128, 64, 2, 2, 2>(), v2_attr<128, 64, 2, 2, 3>(), v2_attr<128, 128, 2, 2, 3>(), v2_attr<256, 128, 4, 2, 2>(),
-      v2_attr<256, 64, 4, 2, 2>(),
+      v2_attr<256, 64, 4, 2, 2>(), v2_attr<256, 288, 4, 3, 2>(),
 #endif
   };
   for (hipError_t x : e)
@@ -520,6 +542,7 @@ hipError_t gemm_v2_launch(const GemmParams& p, hipStream_t s) {
   if (force == 14) return v2_launch<256, 256, 4, 4, 2>(p, s);
   if (force == 15) return v2_launch<256, 192, 4, 3, 2>(p, s);
   if (force == 4) return v2_launch<128, 64, 2, 2, 2>(p, s);
+  if (force == 18) return v2_launch<256, 288, 4, 3, 2>(p, s);
   // register-staged variants (hints 41..43): K % 64 == 0 only
   if (force >= 41 && force <= 43 && (p.K & 63) == 0) {
     if (force == 43) return v2_launch<128, 192, 4, 2, 2, 0, true>(p, s);
@@ -551,6 +574,9 @@ int gemm_v2_auto_tile(const GemmParams& p) {
   // the stage-4 projection, N = K = 1152, stays on 128x64: 43 vs 50 us): the 128x192 tile re-reads the A panel N/192 instead of
   // N/64 times through the L2->LDS path that bounds this kernel (measured +14 % / +16 % on those two shapes) - when it still fills
   // the chip (a batch-1 encoder call has 96 such tiles: 36.5 us vs 25.0 us on 64x64 tiles)
+  // (a 256x288 tile - fc2 of stage 3 at batch 8 as exactly one 12-wave workgroup per CU, 43 % fewer L2->LDS bytes per flop, 5 instead of 8
+  // fragment reads per 6 MFMAs - was measured in round 3: 158 vs 110 us alone, 153 vs 123 us in the pipeline.  One workgroup per CU leaves
+  // nobody to cover the vmcnt + barrier of every K tile; hint 18 in SAM2MI_EXPERIMENTAL builds.)
   if (p.N % 192 == 0 && (p.K >= 2048 || (p.K >= 1024 && p.N >= 2304)) && tiles_of(p, 128, 192) >= 320) return 3;      // stage-4 fc2 at batch 8: 384 tiles, 121 vs 138 us on 128x128
   const int n128 = ((p.N + 127) / 128) * 128;
   const long t128 = tiles_of(p, 128, 128);

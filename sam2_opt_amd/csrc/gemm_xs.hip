@@ -41,7 +41,9 @@ constexpr int NST = 3;                   // two stages in flight while one is co
 constexpr int MAX_COLS = 1152;           // output columns per workgroup (bias table in LDS)
 constexpr int MAX_SCALE = 576;           // of which at most this many leading ones carry a column scale
 constexpr int LDS_B = NST * STAGE_B + (MAX_COLS + MAX_SCALE) * 4;       // 129,792 B
-template <int K> constexpr int frag_batch() { return K == 144 ? 5 : 6; }   // fragments per LDS read batch (double-buffered)
+// fragments per LDS read batch (double-buffered); TIGHT (K = 576, weight split, f32 output: 144 X registers + two accumulators + the
+// prefetched residual) takes batches of 4 to stay inside the 256 registers of two waves per SIMD
+template <int K, bool TIGHT = false> constexpr int frag_batch() { return K == 144 ? 5 : TIGHT ? 4 : 6; }
 
 // GELU: erf-GELU on the row-major columns; F32: f32 output (+ residual) instead of f16 for the row-major columns
 // ABL != 0: timing ablations (wrong results; tuning aid): 1 no LDS-DMA in the loop, 2 no MFMA, 3 no output stores
@@ -54,7 +56,7 @@ template <int K, bool GELU, bool F32, int ABL = 0, bool WS = false>
 __global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams p) {
   constexpr int KS = K / 16;             // k-steps = pieces per chunk
   constexpr int CPS = STAGE_PIECES / KS; // chunks (of 32 output columns) per stage
-  constexpr int FB = frag_batch<K>();
+  constexpr int FB = frag_batch<K, (K == 576 && WS && F32)>();
   constexpr int LS = (WS && CPS == 1) ? 2 : 1;      // ring stages per loop iteration
   constexpr int LCS = WS ? 1 : 0;                   // log2(physical chunks per logical chunk)
   static_assert(KS * CPS == STAGE_PIECES, "K must divide 576");
@@ -142,7 +144,27 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams 
     for (int e = 0; e < 4; ++e) { sa[e] = b0[e]; sa[4 + e] = b1[e]; sa[8 + e] = b2[e]; sa[12 + e] = b3[e]; }
     return sa;
   };
-  auto row_fin = [&](const f32x16& sa, int n0) {
+  // f32 residual of this wave's 32 tokens x 32 columns, loaded BEFORE the DMA issue and the chain, by inline-asm loads that the
+  // compiler does not track, and retired by a COUNTED s_waitcnt in front of row_fin (res_wait<pieces issued since>).  With an
+  // LDS-DMA in flight hipcc waits vmcnt(0) at the use of any ordinary global_load result (cdna_hip_programming.md, glds notes): the
+  // loads inside row_fin drained the two ring stages in flight once per 8-column group - the projection kernel spent 51 % of its
+  // wave cycles in s_waitcnt (profiles/r03d_util.md).  Addresses are clamped (rows past M / columns past N are never stored).
+  struct Res { f32x4 v[4]; };
+  auto res_load = [&](int n0) {
+    Res r;
+    const float* rp = p.res + (size_t)min(tok0 + fr, p.M - 1) * p.ldres;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const float* q = rp + min(n0 + 16 * ks + 8 * fh, p.N - 8);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.v[2 * ks]) : "v"(q) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(r.v[2 * ks + 1]) : "v"(q) : "memory");
+    }
+    return r;
+  };
+  auto res_wait = [](Res& r, auto younger) {        // every vector-memory operation older than the youngest `younger` ones has retired
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]) : "n"(decltype(younger)::value) : "memory");
+  };
+  auto row_fin = [&](const f32x16& sa, int n0, const Res& res) {
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = GELU ? gelu_erf_fast(sa[r]) : sa[r];
@@ -165,10 +187,8 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams 
           f32x4 a = {v[8 * ks], v[8 * ks + 1], v[8 * ks + 2], v[8 * ks + 3]};
           f32x4 b = {v[8 * ks + 4], v[8 * ks + 5], v[8 * ks + 6], v[8 * ks + 7]};
           if (p.res) {
-            const float* rp = p.res + (size_t)tok * p.ldres + n;
-            const f32x4 ra = *reinterpret_cast<const f32x4*>(rp), rb = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { a[e] += ra[e]; b[e] += rb[e]; }
+            for (int e = 0; e < 4; ++e) { a[e] += res.v[2 * ks][e]; b[e] += res.v[2 * ks + 1][e]; }
           }
           *reinterpret_cast<f32x4*>(op) = a;
           *reinterpret_cast<f32x4*>(op + 4) = b;
@@ -235,6 +255,8 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams 
       if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
       __builtin_amdgcn_s_barrier();
+      Res res;
+      if (F32 && p.res && row) res = res_load(n0);
       issue(st + 2);
       f32x16 sa, sc = zero16();
       if (row) { sa = row_init(n0); chain(smem + ((st - st_lo) % NST) * STAGE_B + rd_perm, sa, std::false_type{}); }
@@ -243,7 +265,12 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams 
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
       __builtin_amdgcn_s_barrier();
       issue(st + 3);
-      if (row) { chain(smem + ((st + 1 - st_lo) % NST) * STAGE_B + rd_perm, sc, std::false_type{}); fold(sa, sc); row_fin(sa, n0); }
+      if (row) {
+        chain(smem + ((st + 1 - st_lo) % NST) * STAGE_B + rd_perm, sc, std::false_type{});
+        fold(sa, sc);
+        if (F32 && p.res) res_wait(res, std::integral_constant<int, 2 * PPW>{});       // younger: the pieces of stages st + 2 and st + 3
+        row_fin(sa, n0, res);
+      }
       else { chain(smem + ((st + 1 - st_lo) % NST) * STAGE_B + rd_nat, sc, std::true_type{}); fold(sa, sc); trans_fin(sa, n0); }
     }
   } else {
@@ -254,11 +281,17 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams 
     //   pieces(st) | stores(st-2) | pieces(st+1) | stores(st-1)          (5 pieces per stage; >= 2 stores per logical chunk)
     // vmcnt retires in order, so with N outstanding allowed, N <= (operations younger than pieces(st)) keeps every piece of
     // stage st complete: 5 in the first iteration, 5 + SPS in the second, 5 + 2 SPS afterwards - without waiting for the
-    // store acknowledgements.  M % 256 != 0: some waves store nothing -> 5.
+    // store acknowledgements.  M % 256 != 0: some waves store nothing -> 5.  (The residual loads of the f32 variants are further
+    // younger operations: the counts stay valid.)
     if (st == st_lo || (p.M & (32 * NW - 1))) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
     else if (st == st_lo + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + SPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + 2 * SPS) : "memory");
     __builtin_amdgcn_s_barrier();                         // ... for every wave; everyone is past stage st-1 -> its slot is free
+    Res res[F32 ? (CPS >> LCS) : 1];                      // residuals of every chunk of the stage, in front of the DMA issue
+    if (F32 && p.res) {
+#pragma unroll
+      for (int c = 0; c < CPS; c += 1 << LCS) res[c >> LCS] = res_load(min(((st * CPS + c) >> LCS) * 32, p.N - 8));
+    }
     if (ABL != 1) issue(st + 2);
     const char* sb = smem + ((st - st_lo) % NST) * STAGE_B;
 #pragma unroll
@@ -269,7 +302,8 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_xs_kernel(const GemmXsParams 
         f32x16 sa = row_init(n0);
         chain(sb + c * KS * 1024 + rd_perm, sa, std::false_type{});
         if (WS) { f32x16 sc = zero16(); chain(sb + (c + 1) * KS * 1024 + rd_perm, sc, std::false_type{}); fold(sa, sc); }
-        row_fin(sa, n0);
+        if (F32 && p.res) res_wait(res[c >> LCS], std::integral_constant<int, PPW>{});      // younger: the pieces of stage st + 2 (and stores)
+        row_fin(sa, n0, res[F32 ? (c >> LCS) : 0]);
       } else {
         f32x16 sa = trans_init(n0);
         chain(sb + c * KS * 1024 + rd_nat, sa, std::true_type{});
