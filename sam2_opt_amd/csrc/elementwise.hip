@@ -304,6 +304,22 @@ __global__ void round_bf16_kernel(const float* __restrict__ in, float* __restric
   out[i] = __uint_as_float(u);
 }
 
+// out = bf16_round(x + [flag <= 0] * v[c]): the "+ (1 - appearing) * no_obj_embed_spatial" of _encode_new_memory and the bf16 storage of
+// the memory bank (sam2_base_official.py:1018-1024, sam2_video_predictor_official.py:887) in one launch; x is left as it is
+__global__ void add_rowvec_round_bf16_kernel(const float* __restrict__ x, const float* __restrict__ v, int C, const float* __restrict__ flag,
+                                             float* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = (flag[0] > 0.f) ? 0.f : 1.f;
+  const float f = x[i] + g * v[i % C];
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7F800000u) != 0x7F800000u) {
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    u &= 0xFFFF0000u;
+  }
+  out[i] = __uint_as_float(u);
+}
+
 __global__ void fill_f32_kernel(float* p, float v, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -391,6 +407,11 @@ hipError_t add_rowvec_launch(float* x, int ld, const float* v, int M, int C, con
 }
 hipError_t round_bf16_launch(const float* in, float* out, size_t n, hipStream_t s) {
   round_bf16_kernel<<<grid1d(n), dim3(256), 0, s>>>(in, out, n);
+  return hipGetLastError();
+}
+hipError_t add_rowvec_round_bf16_launch(const float* x, const float* v, int M, int C, const float* flag, float* out, hipStream_t s) {
+  const size_t n = (size_t)M * C;
+  add_rowvec_round_bf16_kernel<<<grid1d(n), dim3(256), 0, s>>>(x, v, C, flag, out, n);
   return hipGetLastError();
 }
 hipError_t fill_f32_launch(float* p, float v, size_t n, hipStream_t s) {

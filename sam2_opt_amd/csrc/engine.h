@@ -255,7 +255,8 @@ struct sam2mi_ctx {
   float* d_pm10 = nullptr;         // [2]: {+10 / -10 object score of a mask input, scratch}
   int* d_flag = nullptr;
   int fill_hole_area = 0;          // sam2mi_set_fill_hole_area: 0 = off (SAM2Base.fill_hole_area, build_sam.py:129)
-  float* d_masks = nullptr; float* d_iou = nullptr; float* d_obj = nullptr; float* d_mtok = nullptr;
+  float* d_masks = nullptr; float* d_iou = nullptr; float* d_obj = nullptr;
+  int dec_T = 0;                   // tokens per prompt of the last decoder pass (layout of d_tok)
   float* d_low_multi = nullptr; float* d_low_sel = nullptr; float* d_tok_sel = nullptr; int* d_best = nullptr; float* d_iou_sel = nullptr;
   float* d_ptr = nullptr; float* d_pts = nullptr; int* d_labels = nullptr;
   // memory encoder

@@ -120,7 +120,9 @@ extern "C" int sam2mi_mask_decoder(sam2mi_ctx* ctx, void* stream, const float* s
     CHKI(decoder_forward(ctx, s, in, nb, T));
     if (masks) CHK(hipMemcpyAsync(masks + (size_t)n0 * 4 * 65536, ctx->d_masks, (size_t)nb * 4 * 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (iou_pred) CHK(hipMemcpyAsync(iou_pred + n0 * 4, ctx->d_iou, (size_t)nb * 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (mask_tokens_out) CHK(hipMemcpyAsync(mask_tokens_out + (size_t)n0 * 1024, ctx->d_mtok, (size_t)nb * 1024 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (mask_tokens_out)      // hs[:, 2:6] of every prompt (mask_decoder.py:280-281), straight from the token buffer
+      CHK(hipMemcpy2DAsync(mask_tokens_out + (size_t)n0 * 1024, (size_t)4 * 256 * sizeof(float), ctx->d_tok + 2 * 256, (size_t)T * 256 * sizeof(float),
+                           (size_t)4 * 256 * sizeof(float), nb, hipMemcpyDeviceToDevice, s));
     if (object_score_logits) CHK(hipMemcpyAsync(object_score_logits + n0, ctx->d_obj, (size_t)nb * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   return 0;
@@ -277,13 +279,17 @@ extern "C" int sam2mi_video_encode_u8(sam2mi_ctx* ctx, void* stream, const uint8
 // `fill_before_outputs`: hole filling of the stored low-res mask (fill_holes_in_mask_scores on pred_masks,
 // sam2_video_predictor_official.py:889-894) happens here; a tracked frame passes `mem_feat_slot >= 0` to run its
 // memory encoder on the UNFILLED mask first, as track_step does (sam2_base_official.py:1151-1166 precedes :889).
-// `n`: which prompt / object of the batched decoder pass (results in ctx->d_masks [n], d_iou [n], d_obj [n], d_mtok [n]).
+// `n`: which prompt / object of the batched decoder pass (results in ctx->d_masks [n], d_iou [n], d_obj [n], tokens 2..5 of d_tok [n]).
+// The caller's copies of the selected mask, the pointer and the score are written by the kernels that produce them (no copy launches
+// on the per-frame path, where every launch of the tracking stream queues behind a kernel of the encoder stream).
 static int sam_heads_finish(sam2mi_ctx* ctx, hipStream_t s, int multimask, int bank_slot, const sam2mi_frame_out* out,
                             int mem_feat_slot = -1, int n = 0) {
   sam2mi_ctx::BankSlot& bk = ctx->bank[bank_slot];
   const float* d_obj = ctx->d_obj + n;
-  CHK(select_mask_launch(ctx->d_masks + (size_t)n * 4 * 65536, ctx->d_iou + n * 4, d_obj, ctx->d_mtok + (size_t)n * 1024, multimask, ctx->d_best + 2,
-                         0.05f, 0.98f, ctx->d_low_multi, bk.low_mask, ctx->d_tok_sel, ctx->d_best, ctx->d_iou_sel, s));
+  const bool fill = ctx->fill_hole_area > 0;
+  CHK(select_mask_launch(ctx->d_masks + (size_t)n * 4 * 65536, ctx->d_iou + n * 4, d_obj, ctx->d_tok + ((size_t)n * ctx->dec_T + 2) * 256, multimask, ctx->d_best + 2,
+                         0.05f, 0.98f, ctx->d_low_multi, bk.low_mask, ctx->d_tok_sel, ctx->d_best, ctx->d_iou_sel, s,
+                         (out && !fill) ? out->low_res_masks : nullptr));
   // obj_ptr = MLP3(token) gated by the object score (sam2_base_official.py:474-484)
   {
     Mlp3Batch B;
@@ -294,20 +300,17 @@ static int sam_heads_finish(sam2mi_ctx* ctx, hipStream_t s, int multimask, int b
     for (int i = 0; i < 3; ++i) { g.W[i] = ctx->ptr_proj[i].w; g.b[i] = ctx->ptr_proj[i].b; }
     CHK(mlp3_launch(B, s));
   }
-  CHK(gate_obj_ptr_launch(bk.obj_ptr, ctx->no_obj_ptr, d_obj, 256, s));
-  CHK(hipMemcpyAsync(bk.obj_score, d_obj, sizeof(float), hipMemcpyDeviceToDevice, s));
+  CHK(gate_obj_ptr_launch(bk.obj_ptr, ctx->no_obj_ptr, d_obj, 256, s, out ? out->obj_ptr : nullptr, bk.obj_score, out ? out->object_score_logits : nullptr));
   if (mem_feat_slot >= 0) CHKI(sam2mi_video_encode_memory(ctx, (void*)s, mem_feat_slot, bank_slot, 0));
-  if (ctx->fill_hole_area > 0) {
+  if (fill) {
     CHK(fill_holes_launch(bk.low_mask, ctx->d_fill_tmp, 1, 256, 256, ctx->fill_hole_area, s));
     CHK(hipMemcpyAsync(bk.low_mask, ctx->d_fill_tmp, 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   if (out) {
     const int nm = multimask ? 3 : 1;
-    if (out->low_res_masks) CHK(hipMemcpyAsync(out->low_res_masks, bk.low_mask, 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out->low_res_masks && fill) CHK(hipMemcpyAsync(out->low_res_masks, bk.low_mask, 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out->low_res_multimasks) CHK(hipMemcpyAsync(out->low_res_multimasks, ctx->d_low_multi, (size_t)nm * 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out->ious) CHK(hipMemcpyAsync(out->ious, ctx->d_iou_sel, nm * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (out->obj_ptr) CHK(hipMemcpyAsync(out->obj_ptr, bk.obj_ptr, 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (out->object_score_logits) CHK(hipMemcpyAsync(out->object_score_logits, d_obj, sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out->best_idx) CHK(hipMemcpyAsync(out->best_idx, ctx->d_best, sizeof(int), hipMemcpyDeviceToDevice, s));
   }
   return 0;
@@ -390,8 +393,7 @@ extern "C" int sam2mi_video_mask(sam2mi_ctx* ctx, void* stream, int feat_slot, c
   CHKI(sam_heads_finish(ctx, s, 0, bank_slot, nullptr));           // single-mask path: token 0 -> obj_ptr, gated by the decoder's score
   // the mask decides whether the object is there (:527-535): score = +-10, pointer gated once more
   CHK(flag_to_score_launch(ctx->d_flag, 10.f, -10.f, ctx->d_pm10, s));
-  CHK(gate_obj_ptr_launch(bk.obj_ptr, ctx->no_obj_ptr, ctx->d_pm10, 256, s));
-  CHK(hipMemcpyAsync(bk.obj_score, ctx->d_pm10, sizeof(float), hipMemcpyDeviceToDevice, s));
+  CHK(gate_obj_ptr_launch(bk.obj_ptr, ctx->no_obj_ptr, ctx->d_pm10, 256, s, out ? out->obj_ptr : nullptr, bk.obj_score, out ? out->object_score_logits : nullptr));
   // low-res output = antialiased 4x down-sampling of mask * 20 - 10 (:503-511)
   CHK(aa_down4_launch(mask1024, S1, 20.f, -10.f, bk.low_mask, s));
   if (ctx->fill_hole_area > 0) {
@@ -400,8 +402,6 @@ extern "C" int sam2mi_video_mask(sam2mi_ctx* ctx, void* stream, int feat_slot, c
   }
   if (out) {
     if (out->low_res_masks) CHK(hipMemcpyAsync(out->low_res_masks, bk.low_mask, 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (out->obj_ptr) CHK(hipMemcpyAsync(out->obj_ptr, bk.obj_ptr, 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (out->object_score_logits) CHK(hipMemcpyAsync(out->object_score_logits, ctx->d_pm10, sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   return 0;
 }
@@ -438,7 +438,7 @@ extern "C" int sam2mi_image_predict_ex(sam2mi_ctx* ctx, void* stream, int feat_s
       // MaskDecoder._dynamic_multimask_via_stability (mask_decoder.py:346-382); "object present" forced on: no gating here
       CHK(fill_f32_launch(ctx->d_t1, 1.f, 1, s));
       for (int n = 0; n < nb; ++n) {
-        CHK(select_mask_launch(ctx->d_masks + (size_t)n * 4 * 65536, ctx->d_iou + n * 4, ctx->d_t1, ctx->d_mtok + (size_t)n * 1024, 0, ctx->d_best + 2, 0.05f,
+        CHK(select_mask_launch(ctx->d_masks + (size_t)n * 4 * 65536, ctx->d_iou + n * 4, ctx->d_t1, ctx->d_tok + ((size_t)n * T + 2) * 256, 0, ctx->d_best + 2, 0.05f,
                                0.98f, nullptr, ctx->d_low_sel, ctx->d_tok_sel, ctx->d_best, ctx->d_iou_sel, s));
         if (masks_out) CHK(hipMemcpyAsync(masks_out + (size_t)(n0 + n) * 65536, ctx->d_low_sel, 65536 * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (iou_out) CHK(hipMemcpyAsync(iou_out + (n0 + n), ctx->d_iou_sel, sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -464,8 +464,7 @@ extern "C" int sam2mi_video_encode_memory(sam2mi_ctx* ctx, void* stream, int fea
   // inside the first conv of the mask down-sampler, the 4-MB tensor is never materialised
   CHKI(memenc_forward(ctx, s, ctx->feats[feat_slot].feat2, nullptr, ctx->m_out, bk.low_mask, is_mask_from_pts ? 1 : 0));
   // + (1 - appearing) * no_obj_embed_spatial, then the bf16 rounding of the memory bank
-  CHK(add_rowvec_launch(ctx->m_out, 64, ctx->no_obj_embed_spatial, 4096, 64, bk.obj_score, s));
-  CHK(round_bf16_launch(ctx->m_out, bk.mem, (size_t)4096 * 64, s));
+  CHK(add_rowvec_round_bf16_launch(ctx->m_out, ctx->no_obj_embed_spatial, 4096, 64, bk.obj_score, bk.mem, s));
   return 0;
 }
 

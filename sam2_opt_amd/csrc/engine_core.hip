@@ -1155,7 +1155,6 @@ static int alloc_workspaces(sam2mi_ctx* ctx) {
   ALLOC(ctx->d_masks, float, (size_t)DEC_MAX_N * 4 * 65536);
   ALLOC(ctx->d_iou, float, DEC_MAX_N * 4 + 8);
   ALLOC(ctx->d_obj, float, DEC_MAX_N + 8);
-  ALLOC(ctx->d_mtok, float, (size_t)DEC_MAX_N * 4 * 256);
   ALLOC(ctx->d_low_multi, float, 3 * 65536);
   ALLOC(ctx->d_low_sel, float, 65536);
   ALLOC(ctx->d_tok_sel, float, 256);

@@ -203,7 +203,8 @@ static int refresh_key_operands(sam2mi_ctx* ctx, hipStream_t s, const float* pos
 // keys_stride 0: one image shared by all prompts, the repeat_image case of sam2_image_predictor.py:564-579),
 // in.dense_tok [dense_rows,256] dense prompt embedding added to it (dense_rows = 1: broadcast no_mask_embed, 4096: per token;
 // null: none), in.pos_tok [4096,256] shared or [N,4096,256], in.tokens [N,T,256], hr0 [65536,32] / hr1 [16384,64] per prompt or shared.
-// Results land in ctx->d_masks [N,4,65536], d_iou [N,4], d_mtok [N,4,256], d_obj [N].
+// Results land in ctx->d_masks [N,4,65536], d_iou [N,4], d_obj [N]; the output tokens stay in ctx->d_tok [N,T,256] (hs: [0] object
+// score token, [1] IoU token, [2..5] mask tokens; ctx->dec_T = T).
 int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, int T) {
   PlanGroup plan_group(GRP_DEC);
   if (T < 6 || T > 64) return sam2mi_set_error(ctx, "decoder_forward", "token count out of range (6..64)");
@@ -214,8 +215,8 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
     CHK(cast_add_launch(in.keys_tok + (size_t)n * in.keys_stride, 256, in.dense_tok ? in.dense_tok + (size_t)n * in.dense_stride : nullptr, 256,
                         in.dense_rows >= 4096 ? 0 : 1, in.dense_tok ? 1.f : 0.f, 4096, 256, nullptr, 0, ctx->d_keys + (size_t)n * 4096 * 256, 256, s, ctx->lo16));
   const float* query_pe = in.tokens;             // the prompt tokens as they came in (transformer.py:128: query_pe = point_embedding), read-only
-  CHK(hipMemcpyAsync(ctx->d_tok, in.tokens, (size_t)R * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-  float* q = ctx->d_tok;
+  float* q = ctx->d_tok;                         // first written by the output projection of layer 0's self attention (which REPLACES the queries)
+  ctx->dec_T = T;
   for (int l = 0; l < 2; ++l) {
     const DecLayerW& L = ctx->dec[l];
     // ---- token self attention (layer 0: no pe, output replaces the queries; transformer.py:186-193)
@@ -223,9 +224,10 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
     {
       SmallLinBatch B;
       B.n = 3;
-      B.d[0] = mk_lin(q, 256, L.self_attn.q, ctx->d_t1, 256, R, 0, nullptr, 0, qpe);
-      B.d[1] = mk_lin(q, 256, L.self_attn.k, ctx->d_t2, 256, R, 0, nullptr, 0, qpe);
-      B.d[2] = mk_lin(q, 256, L.self_attn.v, ctx->d_t3, 256, R, 0);
+      const float* qin = l == 0 ? in.tokens : q;       // layer 0 reads the prompt tokens where they are (no copy into d_tok)
+      B.d[0] = mk_lin(qin, 256, L.self_attn.q, ctx->d_t1, 256, R, 0, nullptr, 0, qpe);
+      B.d[1] = mk_lin(qin, 256, L.self_attn.k, ctx->d_t2, 256, R, 0, nullptr, 0, qpe);
+      B.d[2] = mk_lin(qin, 256, L.self_attn.v, ctx->d_t3, 256, R, 0);
       CHK(small_linear_batch_launch(B, s));
     }
     CHK(small_attn_launch(ctx->d_t1, 256, ctx->d_t2, 256, ctx->d_t3, 256, ctx->d_t4, 256, T, T, 8, 32, N, (size_t)T * 256, (size_t)T * 256,
@@ -264,9 +266,7 @@ int decoder_forward(sam2mi_ctx* ctx, hipStream_t s, const DecoderIn& in, int N, 
   CHKI(refresh_key_operands(ctx, s, in.pos_tok, in.pos_shared, N));
   CHKI(t2i_attention(ctx, s, ctx->fin_q, ctx->fin_k, ctx->fin_v, ctx->fin_o, N, T, query_pe));
   CHKI(tok_ln(ctx, s, q, ctx->fin_norm, R));
-  // hs = q: per prompt [0] obj score token, [1] iou token, [2..5] mask tokens
-  CHK(hipMemcpy2DAsync(ctx->d_mtok, (size_t)4 * 256 * sizeof(float), q + 2 * 256, (size_t)T * 256 * sizeof(float), (size_t)4 * 256 * sizeof(float), N,
-                       hipMemcpyDeviceToDevice, s));
+  // hs = q: per prompt [0] obj score token, [1] iou token, [2..5] mask tokens (read in place by the heads below and by select_mask)
   // ---- upscaling: ConvT(256->64) + hr1 -> LN2d -> GELU -> ConvT(64->32) + hr0 -> GELU  (mask_decoder.py:283-288)
   {
     GemmParams p = lin_params(ctx->d_keys16, 256, M, ctx->dc1);

@@ -187,7 +187,7 @@ __global__ void stability_count_kernel(const float* __restrict__ mask0, float de
 __global__ void select_mask_kernel(const float* __restrict__ masks, const float* __restrict__ iou, const float* __restrict__ obj,
                                    const float* __restrict__ tokens, int multimask, const int* __restrict__ counts,
                                    float stab_thresh, float* low_multi, float* low_sel, float* tok_sel, int* best_idx,
-                                   float* iou_out) {
+                                   float* iou_out, float* low_sel2) {
   const bool appearing = obj[0] > 0.f;
   int bm = 1;
   float bv = iou[1];
@@ -205,7 +205,9 @@ __global__ void select_mask_kernel(const float* __restrict__ masks, const float*
   }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 65536) {
-    low_sel[i] = appearing ? masks[(size_t)best * 65536 + i] : NO_OBJ_SCORE;
+    const float sel = appearing ? masks[(size_t)best * 65536 + i] : NO_OBJ_SCORE;
+    low_sel[i] = sel;
+    if (low_sel2) low_sel2[i] = sel;                   // the caller's copy of the selected mask
     if (low_multi) {
       if (multimask) {
 #pragma unroll
@@ -225,11 +227,20 @@ __global__ void select_mask_kernel(const float* __restrict__ masks, const float*
   }
 }
 
-__global__ void gate_obj_ptr_kernel(float* ptr, const float* __restrict__ no_obj_ptr, const float* __restrict__ obj, int C) {
+// also hands the pointer / the score on to up to three more places (bank slot score, caller's outputs): no copy launches behind it
+__global__ void gate_obj_ptr_kernel(float* ptr, const float* __restrict__ no_obj_ptr, const float* __restrict__ obj, int C, float* ptr_out,
+                                    float* score_out, float* score_out2) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float lam = obj[0] > 0.f ? 1.f : 0.f;
-  ptr[c] = lam * ptr[c] + (1.f - lam) * no_obj_ptr[c];
+  const float sc = obj[0];
+  const float lam = sc > 0.f ? 1.f : 0.f;
+  const float v = lam * ptr[c] + (1.f - lam) * no_obj_ptr[c];
+  ptr[c] = v;
+  if (ptr_out) ptr_out[c] = v;
+  if (c == 0) {
+    if (score_out) score_out[0] = sc;
+    if (score_out2) score_out2[0] = sc;
+  }
 }
 
 __global__ void mem_assemble_kernel(const MemAssembleParams p) {
@@ -316,18 +327,19 @@ hipError_t upscale_glue_launch(const float* g, int Hin, int C, const float* bias
 }
 hipError_t select_mask_launch(const float* masks, const float* iou, const float* obj, const float* tokens, int multimask,
                               int* stab_counts, float stab_delta, float stab_thresh, float* low_multi, float* low_sel,
-                              float* tok_sel, int* best_idx, float* iou_out, hipStream_t s) {
+                              float* tok_sel, int* best_idx, float* iou_out, hipStream_t s, float* low_sel2) {
   if (!multimask && stab_counts) {
     hipError_t e = hipMemsetAsync(stab_counts, 0, 2 * sizeof(int), s);
     if (e != hipSuccess) return e;
     stability_count_kernel<<<dim3(256), dim3(256), 0, s>>>(masks, stab_delta, stab_counts);
   }
   select_mask_kernel<<<dim3(256), dim3(256), 0, s>>>(masks, iou, obj, tokens, multimask, multimask ? nullptr : stab_counts,
-                                                     stab_thresh, low_multi, low_sel, tok_sel, best_idx, iou_out);
+                                                     stab_thresh, low_multi, low_sel, tok_sel, best_idx, iou_out, low_sel2);
   return hipGetLastError();
 }
-hipError_t gate_obj_ptr_launch(float* ptr, const float* no_obj_ptr, const float* obj, int C, hipStream_t s) {
-  gate_obj_ptr_kernel<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(ptr, no_obj_ptr, obj, C);
+hipError_t gate_obj_ptr_launch(float* ptr, const float* no_obj_ptr, const float* obj, int C, hipStream_t s, float* ptr_out, float* score_out,
+                               float* score_out2) {
+  gate_obj_ptr_kernel<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(ptr, no_obj_ptr, obj, C, ptr_out, score_out, score_out2);
   return hipGetLastError();
 }
 hipError_t mem_assemble_launch(const MemAssembleParams& p, hipStream_t s) {

@@ -35,6 +35,7 @@ hipError_t transpose_f32_launch(const float* in, float* out, int batch, int R, i
 hipError_t add_rowvec_launch(float* x, int ld, const float* v, int M, int C, const float* flag, hipStream_t s);
 // round-to-nearest-even to bf16 precision, kept as f32 (the reference stores the memory bank as bf16)
 hipError_t round_bf16_launch(const float* in, float* out, size_t n, hipStream_t s);
+hipError_t add_rowvec_round_bf16_launch(const float* x, const float* v, int M, int C, const float* flag, float* out, hipStream_t s);   // x contiguous [M, C]
 // fill f16 / f32
 hipError_t fill_f32_launch(float* p, float v, size_t n, hipStream_t s);
 
@@ -110,9 +111,10 @@ hipError_t upscale_glue_launch(const float* g, int Hin, int C, const float* bias
 //  dynamic stability fallback (stab_counts: 2-int scratch; null disables the fallback).
 hipError_t select_mask_launch(const float* masks, const float* iou, const float* obj, const float* tokens, int multimask,
                               int* stab_counts, float stab_delta, float stab_thresh, float* low_multi, float* low_sel,
-                              float* tok_sel, int* best_idx, float* iou_out, hipStream_t s);
+                              float* tok_sel, int* best_idx, float* iou_out, hipStream_t s, float* low_sel2 = nullptr);
 // obj_ptr = lam * ptr + (1 - lam) * no_obj_ptr, lam = obj > 0
-hipError_t gate_obj_ptr_launch(float* ptr, const float* no_obj_ptr, const float* obj, int C, hipStream_t s);
+hipError_t gate_obj_ptr_launch(float* ptr, const float* no_obj_ptr, const float* obj, int C, hipStream_t s, float* ptr_out = nullptr,
+                               float* score_out = nullptr, float* score_out2 = nullptr);
 // memory-bank K/V operand assembly: for slot s (0..L-1) rows [s*4096, (s+1)*4096):
 //   kin = f16(feat_s + pos + tpos_s), vin = f16(feat_s); pointer tokens appended after the L frames.
 struct MemAssembleParams {
