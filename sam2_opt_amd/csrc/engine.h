@@ -278,6 +278,7 @@ struct sam2mi_ctx {
   std::map<std::string, ProfAcc> prof_by_kernel;   // the GEMM-family launches again, keyed by kernel instantiation (rocprofv3 names)
   bool use_ks = false;             // accumulator-stationary GEMM for stage-3 fc2 (experimental, SAM2MI_KS=1; parity-tested, not faster end to end)
   bool use_xs = true;              // X-stationary GEMM for K <= 576 linears of the encoder (SAM2MI_NO_XS=1: tiled kernel)
+  int enc_sub = 0;                 // frames per sub-batch of Hiera stages 1-2 inside an encoder pass (0: whole batch, the default - no gain measured; SAM2MI_ENC_SUB)
   bool ln_fuse = false;            // LN1 / LN2 of Hiera blocks computed inside the consumer's operand load (opt-in: SAM2MI_LN_FUSE=1; no end-to-end gain)
   int ln1_fuse_maxc = 0;           // norm1 inside the operand load of the X-stationary QKV kernel for blocks with dim <= this (SAM2MI_LN1_FUSE_MAXC; 0: off)
   bool use_projln = true;          // Hiera stages 1-3: out-projection + residual + norm2 in one kernel (SAM2MI_NO_PROJLN=1: GEMM + LayerNorm)

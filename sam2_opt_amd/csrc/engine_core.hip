@@ -521,6 +521,7 @@ extern "C" int sam2mi_create(const sam2mi_config* cfg, sam2mi_ctx** out) {
   // (205.6 vs 205.7 frames/s): the row is read twice as f32 by every column split, which costs what the separate LayerNorm
   // kernel cost (it runs at 5.5 TB/s) and moves more bytes past the L2.  Opt-in for A/B runs.
   ctx->ln_fuse = !ctx->precise && getenv("SAM2MI_LN_FUSE") != nullptr;
+  if (getenv("SAM2MI_ENC_SUB")) ctx->enc_sub = atoi(getenv("SAM2MI_ENC_SUB"));
   ctx->use_ks = !ctx->precise && getenv("SAM2MI_KS") != nullptr;     // experimental (no end-to-end gain over the tiled kernel on fc2): opt-in
   hipError_t e = gemm_init();
   if (e == hipSuccess) e = flash256_init();

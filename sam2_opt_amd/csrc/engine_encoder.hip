@@ -267,31 +267,89 @@ int hiera_block_forward_generic(sam2mi_ctx* ctx, hipStream_t s, const HieraBlock
   return 0;
 }
 
+// One stage-end: lateral 1x1 conv of the FPN on the stage's output (image_encoder.py:113-114).  `row0`: first token row of the frames in
+// flight inside the level's full-batch lateral buffer (sub-batched stages 1-2).
+static int stage_lateral(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, int M, int level, size_t row0) {
+  CHK(cast_add_launch(ctx->ws_x, b.dim_out, nullptr, 0, 0, 0.f, M, b.dim_out, ctx->ws_a16, b.dim_out, nullptr, 0, s, ctx->lo16));
+  // levels 0 / 1: the lateral composed with conv_s0 / conv_s1 (32 / 64 channels, compact in ws_lat[level]); levels 2 / 3: lateral
+  const Lin16& L = level == 0 ? ctx->neck_s0 : level == 1 ? ctx->neck_s1 : ctx->neck[level];
+  GemmParams p = lin_params(ctx->ws_a16, b.dim_out, M, L);
+  p.out32 = ctx->ws_lat[level] + row0 * L.N; p.ld32 = L.N;
+  CHKI(run_gemm(ctx, s, p));
+  return 0;
+}
+
 // Runs patch embedding + all blocks; fills ctx->ws_lat[0..3] (neck laterals, window-major) and returns
 // the window size of each level's token order in wlev[].
+//
+// Optional (SAM2MI_ENC_SUB = n, off by default): stages 1-2 in SUB-BATCHES of n frames, hiera-large layout only.  Their kernels are
+// HBM-bound launches of 2048+ workgroups that last 250-540 us at batch 8; two frames at a time the same kernels last 65-135 us, which
+// was meant to let the kernels of the tracking stream in more often.  MEASURED, NO GAIN (round 3, same box: 202.0 whole batch, 201.6 /
+// 202.2 frames/s with n = 2 / 4, 195.7 with n = 1): the encoder stream is the critical path and never idle (tools/event_timeline.py,
+// profiles/r03f_event_timeline.txt: passes back to back, 39 ms each beside the tracking against 31.7 ms alone), the rate follows the
+// SUM of the two streams' work, not how it is cut.  Outputs are bitwise those of the whole-batch pass (tests/test_plugs_gpu.py).
+// Stage 1 / 2 outputs of a sub-batch sit at the sub-batch's stage-1 offset of ws_x; they are moved up to their place in the compact
+// stage-2 layout before stage 3 runs on the whole batch.
 static int trunk_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, const uint8_t* img_u8, int B, int wlev[4]) {
   const sam2mi_config& c = ctx->cfg;
   const int G = c.image_size / 4, E = c.embed_dim;
-  int H = G, W = G, wcur = 8;
-  // patch embed (conv 7x7 s4 p3 as im2col GEMM) + position table, written in window-major order
-  if (img_u8) CHK(im2col_patch_u8_launch(img_u8, B, c.image_size, ctx->ws_a16, s, ctx->lo16, ctx->generic));
-  else CHK(im2col_patch_launch(img, B, c.image_size, ctx->ws_a16, s, ctx->lo16, ctx->generic));
-  if (ctx->generic) wcur = G;                    // generic sizes: row-major tokens = one "window" as wide as the grid
-  {
-    GemmParams p = lin_params(ctx->ws_a16, 160, B * G * G, ctx->patch);
-    p.res = ctx->pos_tab; p.ldres = E; p.res_mod = G * G;
-    p.out32 = ctx->ws_x; p.ld32 = E;
-    CHKI(run_gemm(ctx, s, p));
+  const size_t nblk = ctx->blocks.size();
+  // the sub-batched prefix: the blocks in front of the first one that leaves stage 2 (dim_out > 2 E), if no window re-ordering falls
+  // inside it (none does for hiera-large: 8x8 windows, halved to 4x4 by the query pooling of block 2)
+  size_t nprefix = 0;
+  int sub = B;
+  if (!ctx->generic && ctx->enc_sub > 0 && ctx->enc_sub < B) {
+    while (nprefix < nblk && ctx->blocks[nprefix].dim_out <= 2 * E) ++nprefix;
+    int w = 8;
+    bool ok = nprefix > 0 && nprefix < nblk;
+    for (size_t i = 0; ok && i < nprefix; ++i) {
+      if (ctx->blocks[i].q_pool) w /= 2;
+      const int wn = ctx->blocks[i + 1].window;
+      if (wn > 0 && wn != w) ok = false;
+    }
+    if (ok) sub = ctx->enc_sub; else nprefix = 0;
   }
-  int level = 0;
-  for (size_t i = 0; i < ctx->blocks.size(); ++i) {
+  float* const base_x = ctx->ws_x;
+  int H = G, W = G, wcur = 8, level = 0;
+  for (int f0 = 0; f0 < B; f0 += sub) {
+    const int Bs = std::min(sub, B - f0);
+    H = G; W = G; wcur = 8; level = 0;
+    ctx->ws_x = base_x + (size_t)f0 * G * G * E;
+    // patch embed (conv 7x7 s4 p3 as im2col GEMM) + position table, written in window-major order
+    const size_t img_off = (size_t)f0 * 3 * c.image_size * c.image_size;
+    if (img_u8) CHK(im2col_patch_u8_launch(img_u8 + img_off, Bs, c.image_size, ctx->ws_a16, s, ctx->lo16, ctx->generic));
+    else CHK(im2col_patch_launch(img + img_off, Bs, c.image_size, ctx->ws_a16, s, ctx->lo16, ctx->generic));
+    if (ctx->generic) wcur = G;                    // generic sizes: row-major tokens = one "window" as wide as the grid
+    {
+      GemmParams p = lin_params(ctx->ws_a16, 160, Bs * G * G, ctx->patch);
+      p.res = ctx->pos_tab; p.ldres = E; p.res_mod = G * G;
+      p.out32 = ctx->ws_x; p.ld32 = E;
+      CHKI(run_gemm(ctx, s, p));
+    }
+    for (size_t i = 0; i < nprefix; ++i) {
+      const HieraBlockW& b = ctx->blocks[i];
+      CHKI(hiera_block_forward(ctx, s, b, Bs, H, W, wcur));
+      if (b.stage_end) {
+        CHKI(stage_lateral(ctx, s, b, Bs * H * W, level, (size_t)f0 * H * W));
+        wlev[level] = wcur;
+        ++level;
+      }
+    }
+    if (nprefix > 0 && f0 > 0) {                   // up to the compact layout of the prefix's output (destination ends below the source: f0 >= sub)
+      const size_t per_frame = (size_t)H * W * ctx->blocks[nprefix - 1].dim_out;
+      CHK(hipMemcpyAsync(base_x + (size_t)f0 * per_frame, ctx->ws_x, (size_t)Bs * per_frame * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    if (ctx->ws_x != base_x + (size_t)f0 * G * G * E) { ctx->ws_x = base_x; return sam2mi_set_error(ctx, "trunk_forward", "unexpected buffer swap inside the sub-batched prefix"); }
+  }
+  ctx->ws_x = base_x;
+  for (size_t i = nprefix; i < nblk; ++i) {
     const HieraBlockW& b = ctx->blocks[i];
     if (ctx->generic) {
       CHKI(hiera_block_forward_generic(ctx, s, b, B, H, W));
       wcur = W;
     } else CHKI(hiera_block_forward(ctx, s, b, B, H, W, wcur));
     // window size expected by the next block (hieradet.py:243-256: the window lags one block)
-    if (!ctx->generic && i + 1 < ctx->blocks.size()) {
+    if (!ctx->generic && i + 1 < nblk) {
       const int wn = ctx->blocks[i + 1].window;
       if (wn > 0 && wn != wcur) {
         CHK(permute_tokens_launch(ctx->ws_x, ctx->ws_x2, B, H, W, b.dim_out, wcur, wn, nullptr, 0, s));
@@ -300,14 +358,7 @@ static int trunk_forward(sam2mi_ctx* ctx, hipStream_t s, const float* img, const
       }
     }
     if (b.stage_end) {
-      // lateral 1x1 conv of the FPN on this stage's output (image_encoder.py:113-114)
-      const int M = B * H * W;
-      CHK(cast_add_launch(ctx->ws_x, b.dim_out, nullptr, 0, 0, 0.f, M, b.dim_out, ctx->ws_a16, b.dim_out, nullptr, 0, s, ctx->lo16));
-      // levels 0 / 1: the lateral composed with conv_s0 / conv_s1 (32 / 64 channels, compact in ws_lat[level]); levels 2 / 3: lateral
-      const Lin16& L = level == 0 ? ctx->neck_s0 : level == 1 ? ctx->neck_s1 : ctx->neck[level];
-      GemmParams p = lin_params(ctx->ws_a16, b.dim_out, M, L);
-      p.out32 = ctx->ws_lat[level]; p.ld32 = L.N;
-      CHKI(run_gemm(ctx, s, p));
+      CHKI(stage_lateral(ctx, s, b, B * H * W, level, 0));
       wlev[level] = wcur;
       ++level;
     }

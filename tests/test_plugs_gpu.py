@@ -78,6 +78,30 @@ def test_image_encoder_batch8_matches_batch1(sd_large):
         e8.close()
 
 
+def test_image_encoder_sub_batched_stages_1_2_bitwise(sd_large, monkeypatch):
+    """SAM2MI_ENC_SUB = 2: Hiera stages 1-2 of an encoder pass run two frames at a time (engine_encoder.hip, trunk_forward), stage 3 on
+    the whole batch.  Per-token kernels on the same rows: the seven outputs must be bitwise those of the whole-batch pass, for a batch
+    that is a multiple of the sub-batch (6) and for one that is not (5)."""
+    from sam2_opt_amd.native import Engine
+    from sam2_opt_amd.synthetic import synthetic_image_normed
+    imgs = torch.cat([synthetic_image_normed(seed=40 + i) for i in range(6)], dim=0).cuda()
+    e0 = Engine("large", state_dict=sd_large, max_batch=6)
+    try:
+        ref6 = [t.clone() for t in e0.image_encoder(imgs)]
+        ref5 = [t.clone() for t in e0.image_encoder(imgs[:5])]
+    finally:
+        e0.close()
+    monkeypatch.setenv("SAM2MI_ENC_SUB", "2")
+    e2 = Engine("large", state_dict=sd_large, max_batch=6)
+    try:
+        for ref, x in ((ref6, imgs), (ref5, imgs[:5])):
+            got = e2.image_encoder(x)
+            for k in (0, 4, 5, 6):
+                assert torch.equal(got[k], ref[k]), f"output {k} differs with sub-batched stages 1-2 (batch {x.shape[0]})"
+    finally:
+        e2.close()
+
+
 def test_set_image_e2e(eng, sd_large, cfg_large):
     from oracle import sam2_ref as R
     rs = np.random.RandomState(5)

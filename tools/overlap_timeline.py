@@ -5,7 +5,13 @@ tracking path's except for the shared GEMM / LayerNorm instantiations, which are
     python tools/overlap_timeline.py <...kernel_trace.csv> [frames_in_timed_region]
 
 Prints, for the last `frames` frames' worth of wall time: wall, union busy, per-queue busy, time both queues run, time only one runs,
-time the chip is idle, and a 1-ms-bucket strip of one encoder-batch period (E = encoder only, T = tracking only, B = both, . = idle)."""
+time the chip is idle, and a 1-ms-bucket strip of one encoder-batch period (E = encoder only, T = tracking only, B = both, . = idle).
+
+CAUTION (found at the end of round 3): under rocprofv3 --kernel-trace a launch costs the host ~60 us instead of ~3 us, the 341 launches of
+an encoder pass take ~20 ms to enqueue, and the launching thread - not the GPU - paces the run: the tracking queue runs dry while the pass
+is being enqueued (the "21-ms tracked frame" and the idle stretches of the encoder queue in this tool's output).  The schedule of the
+un-profiled run is what tools/event_timeline.py measures with in-stream HIP events: encoder passes back to back, every tracked frame
+beside one.  This tool is kept for the per-kernel "wait-before" table only."""
 import collections
 import csv
 import sys
