@@ -80,8 +80,12 @@ static __device__ __forceinline__ float gelu_nc(float x) {
 //                  Y^T += W2_j P_j          [MFMA]
 // All fragments of both products are read from LDS at the top of the iteration (one wave per SIMD has the registers), the
 // first phase is laid out with sched_group_barrier as (1 MFMA, 1 DMA piece, a slice of the VALU work) groups.
+// C = 144 with ONE token tile per wave (TN = 1, 3-slot ring): 80 + 36 accumulator / operand registers instead of 160 + 72, so the kernel
+// fits 256 registers and 62 KB of LDS and TWO workgroups share a CU - two waves per SIMD with independent barriers, i.e. the GELU of one
+// beside the MFMA chains of the other (with one wave per SIMD the two phases of an iteration can only overlap inside the wave's own
+// instruction stream).  The weights stream twice as often (128 tokens per workgroup), which the L2 -> LDS path has room for at C = 144.
 template <int C, int TN, int NST>
-__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpFusedParams p) {
+__global__ __launch_bounds__(256, (C == 144 && TN == 1) ? 2 : 1) void mlp_fused_kernel(const MlpFusedParams p) {
   using K = MlpCfg<C, TN, NST>;
   constexpr int NW = K::NW, KS = K::KS, OT = K::OT, H4 = K::H4, NCH = K::NCH, W1P = K::W1P, NP = K::NP, PPW = K::PPW, STAGE_B = K::STAGE_B;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -275,13 +279,15 @@ hipError_t attr_cfg() {
 }
 }  // namespace
 
-// Configurations: C = 144: 64 tokens per wave (256 per workgroup), 19 + 1 padding pieces per chunk, 4-slot ring (82 KiB);
+// Configurations: C = 144: 32 tokens per wave (128 per workgroup), 3-slot ring (62 KiB), 246 registers: two workgroups per CU (the
+// default since round 3; before: 64 tokens per wave, 256 per workgroup, 4-slot ring of 82 KiB, 400 registers, one workgroup per CU);
+// 19 + 1 padding pieces per chunk;
 // C = 288: 32 tokens per wave (128 per workgroup), 36 pieces per chunk, 3-slot ring (113 KiB).
 // C = 576 does not fit: 32 tokens need 144 (X) + 288 (Y^T) of the 512 registers and the compiler spills X into scratch
 // (reloaded inside the MFMA chains behind vmcnt(0), which also drains the DMA ring) - stage 3 stays on the two-GEMM path.
 hipError_t mlp_fused_init() {
-  hipError_t e[3] = {attr_cfg<144, 2, 4>(), attr_cfg<288, 1, 4>(), attr_cfg<288, 1, 3>()};
-  for (int i = 0; i < 3; ++i)
+  hipError_t e[4] = {attr_cfg<144, 2, 4>(), attr_cfg<288, 1, 4>(), attr_cfg<288, 1, 3>(), attr_cfg<144, 1, 3>()};
+  for (int i = 0; i < 4; ++i)
     if (e[i] != hipSuccess) return e[i];
   return hipSuccess;
 }
@@ -305,10 +311,12 @@ hipError_t mlp_fused_pack(const half_t* w1, const half_t* w2, int C, half_t* wpa
 
 // C = 288: a 3-slot ring (113 KB) runs the kernel at the same speed as 4 slots (149 KB) and leaves LDS for a small workgroup of the
 // tracking stream beside it (+0.7 % end to end); SAM2MI_MLP_RING4=1 restores 4 slots
+// C = 144: two workgroups per CU (<144, 1, 3>), 462 -> 346 us per stage-1 launch (round 3); SAM2MI_MLP144_2WG=0 restores <144, 2, 4>
+static bool two_per_cu() { static const bool v = getenv("SAM2MI_MLP144_2WG") ? atoi(getenv("SAM2MI_MLP144_2WG")) != 0 : true; return v; }
 static bool ring4() { static const bool v = getenv("SAM2MI_MLP_RING4") != nullptr; return v; }
 
 const char* mlp_fused_kernel_name(int C) {       // as rocprofv3 prints it
-  if (C == 144) return "mlp_fused_kernel<144, 2, 4>";
+  if (C == 144) return two_per_cu() ? "mlp_fused_kernel<144, 1, 3>" : "mlp_fused_kernel<144, 2, 4>";
   return ring4() ? "mlp_fused_kernel<288, 1, 4>" : "mlp_fused_kernel<288, 1, 3>";
 }
 
@@ -316,7 +324,7 @@ hipError_t mlp_fused_launch(const MlpFusedParams& p, int C, hipStream_t s) {
   if (p.M <= 0) return hipSuccess;
   if ((p.ldx & 7) || (p.ld32 & 3)) return hipErrorInvalidValue;
   switch (C) {
-    case 144: return launch_cfg<144, 2, 4>(p, s);
+    case 144: return two_per_cu() ? launch_cfg<144, 1, 3>(p, s) : launch_cfg<144, 2, 4>(p, s);
     case 288: return ring4() ? launch_cfg<288, 1, 4>(p, s) : launch_cfg<288, 1, 3>(p, s);
     default: return hipErrorInvalidValue;
   }
