@@ -156,17 +156,23 @@ __global__ __launch_bounds__(256, 2) void hiera_attn_kernel(const HieraAttnParam
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = fmaf(sc[r], SPLIT_INV, s[r]);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    constexpr bool V_UP = !(SPLIT && MASK && !SHARE);        // the masked split variant on per-wave tiles is 9 registers over 256 with the V^T prefetch
+    auto read_v = [&]() {
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const half_t* vr = sV + (t * 32 + fr) * VROW + ks * 16 + fh * 4;
-        const half4 lo = *reinterpret_cast<const half4*>(vr);
-        const half4 hi = *reinterpret_cast<const half4*>(vr + 8);
-        vf[t][ks] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
-    __builtin_amdgcn_sched_barrier(0);
+        for (int ks = 0; ks < 2; ++ks) {
+          const half_t* vr = sV + (t * 32 + fr) * VROW + ks * 16 + fh * 4;
+          const half4 lo = *reinterpret_cast<const half4*>(vr);
+          const half4 hi = *reinterpret_cast<const half4*>(vr + 8);
+          vf[t][ks] = half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+    };
+    if constexpr (V_UP) {
+      __builtin_amdgcn_sched_barrier(0);
+      read_v();
+      __builtin_amdgcn_sched_barrier(0);
+    }
     float tmax = -1e30f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -196,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void hiera_attn_kernel(const HieraAttnParam
     }
     l_run += psum;
     // ---- O^T += V^T P^T
+    if constexpr (!V_UP) read_v();
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
 #pragma unroll

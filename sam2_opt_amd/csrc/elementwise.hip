@@ -197,30 +197,36 @@ __global__ void pool_tokens_kernel(const T* __restrict__ in, int ldin, T* __rest
 
 // the same on a 2-term f16 split (hi plane + lo plane lo_off elements behind it, common.h): the maximum of the four VALUES
 // hi + lo * 2^-11, written as the (hi, lo) pair of the token that holds it (exact: a max-pool selects, it does not compute)
+// one thread = 8 consecutive channels (16-B loads / stores of both planes; C % 8 == 0, ldin / ldout / plane offsets multiples of 8)
 __global__ void pool_tokens_split_kernel(const half_t* __restrict__ in, size_t in_lo, int ldin, half_t* __restrict__ out, size_t out_lo, int ldout,
                                          int nwin, int w, int C) {
-  const int hw = w / 2;
+  const int hw = w / 2, C8 = C >> 3;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)nwin * hw * hw * C;
+  const size_t total = (size_t)nwin * hw * hw * C8;
   if (i >= total) return;
-  const int c = (int)(i % C);
-  const size_t ot = i / C;
+  const int c = (int)(i % C8) * 8;
+  const size_t ot = i / C8;
   const int win = (int)(ot / (hw * hw)), p = (int)(ot % (hw * hw));
   const int py = p / hw, px = p % hw;
   const half_t* base = in + ((size_t)win * w * w) * ldin + c;
-  float m = -3.0e38f;
-  half_t mh = (half_t)0.f, ml = (half_t)0.f;
+  float m[8];
+  half8 mh, ml;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { m[e] = -3.0e38f; mh[e] = (half_t)0.f; ml[e] = (half_t)0.f; }
 #pragma unroll
   for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
     for (int dx = 0; dx < 2; ++dx) {
       const half_t* q = base + (size_t)((2 * py + dy) * w + 2 * px + dx) * ldin;
-      const half_t h = q[0], l = q[in_lo];
-      const float v = (float)h + (float)l * SPLIT_INV;
-      if (v > m) { m = v; mh = h; ml = l; }
+      const half8 h = *reinterpret_cast<const half8*>(q), l = *reinterpret_cast<const half8*>(q + in_lo);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = (float)h[e] + (float)l[e] * SPLIT_INV;
+        if (v > m[e]) { m[e] = v; mh[e] = h[e]; ml[e] = l[e]; }
+      }
     }
-  out[ot * ldout + c] = mh;
-  out[ot * ldout + c + out_lo] = ml;
+  *reinterpret_cast<half8*>(out + ot * ldout + c) = mh;
+  *reinterpret_cast<half8*>(out + ot * ldout + c + out_lo) = ml;
 }
 
 // [R, 64] f16 row-major -> [64, ld] (column r = input row r): 64 x 64 tiles through LDS.  The memory tokens as the V^T operand of the
@@ -381,7 +387,8 @@ hipError_t pool_tokens_f16_launch(const half_t* in, int ldin, half_t* out, int l
   return hipGetLastError();
 }
 hipError_t pool_tokens_split_launch(const half_t* in, size_t in_lo, int ldin, half_t* out, size_t out_lo, int ldout, int nwin, int w, int C, hipStream_t s) {
-  pool_tokens_split_kernel<<<grid1d((size_t)nwin * (w / 2) * (w / 2) * C), dim3(256), 0, s>>>(in, in_lo, ldin, out, out_lo, ldout, nwin, w, C);
+  if ((C & 7) || (ldin & 7) || (ldout & 7) || (in_lo & 7) || (out_lo & 7)) return hipErrorInvalidValue;
+  pool_tokens_split_kernel<<<grid1d((size_t)nwin * (w / 2) * (w / 2) * (C / 8)), dim3(256), 0, s>>>(in, in_lo, ldin, out, out_lo, ldout, nwin, w, C);
   return hipGetLastError();
 }
 hipError_t transpose_rows64_f16_launch(const half_t* in, half_t* out, int R, int ld, hipStream_t s) {
