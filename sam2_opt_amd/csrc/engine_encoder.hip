@@ -286,7 +286,7 @@ static int stage_lateral(sam2mi_ctx* ctx, hipStream_t s, const HieraBlockW& b, i
 // HBM-bound launches of 2048+ workgroups that last 250-540 us at batch 8; two frames at a time the same kernels last 65-135 us, which
 // was meant to let the kernels of the tracking stream in more often.  MEASURED, NO GAIN (round 3, same box: 202.0 whole batch, 201.6 /
 // 202.2 frames/s with n = 2 / 4, 195.7 with n = 1): the encoder stream is the critical path and never idle (tools/event_timeline.py,
-// profiles/r03g_event_timeline.txt: passes back to back, 37 ms each beside the tracking against 30.9 ms alone), the rate follows the
+// profiles/*_event_timeline.txt: passes back to back, 37 ms each beside the tracking against 31 ms alone), the rate follows the
 // SUM of the two streams' work, not how it is cut.  Outputs are bitwise those of the whole-batch pass (tests/test_plugs_gpu.py).
 // Stage 1 / 2 outputs of a sub-batch sit at the sub-batch's stage-1 offset of ws_x; they are moved up to their place in the compact
 // stage-2 layout before stage 3 runs on the whole batch.
